@@ -1,0 +1,106 @@
+"""CPU tests: the oracle (oracle/) is pinned to outputs of the REAL reference.
+
+The fixtures under tests/golden/ were produced by tests/golden/make_golden.py, which imports the
+reference's hctr_model / ctc_codec in the build container. These tests re-run the oracle's
+restatement on the same seeded inputs and require agreement: float tolerance for logits
+(CPU conv kernels may differ in summation order between hosts), exact for indices/strings.
+"""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import codec_cases
+from conftest import GOLDEN
+from oracle import ctc_ref, hctr_ref
+
+LOGIT_ATOL = 2e-4     # fp32 CPU-vs-CPU (different thread counts / ISAs); logits are O(10)
+
+
+def _strings():
+    with open(os.path.join(GOLDEN, "model_strings.json")) as f:
+        return json.load(f)
+
+
+def test_synth_known_answers(synth, state_dict):
+    with open(os.path.join(GOLDEN, "synth_kat.json")) as f:
+        kat = json.load(f)
+    assert len(state_dict) == 254 and set(kat) == set(state_dict)
+    for k, v in state_dict.items():
+        a = np.ascontiguousarray(v)
+        assert list(a.shape) == kat[k]["shape"] and str(a.dtype) == kat[k]["dtype"], k
+        if k == "linear.bias":       # contains a float64 mat-vec: allow 1-ulp BLAS differences
+            np.testing.assert_allclose(a.reshape(-1)[:4], kat[k]["head"], rtol=1e-6)
+            continue
+        assert (zlib.crc32(a.tobytes()) & 0xFFFFFFFF) == kat[k]["crc32"], k
+
+
+@pytest.mark.parametrize("name,seed,widths", [("b1w32", 21, [32]), ("b3w67u", 22, [67, 50, 33]),
+                                              ("b2w96", 23, [96, 96])])
+def test_oracle_forward_matches_reference(synth, state_dict, name, seed, widths):
+    g = np.load(os.path.join(GOLDEN, "model_small.npz"))
+    imgs = synth.make_line_images(len(widths), max(widths), seed)
+    x = synth.normalize_pad(imgs, widths)
+    taps = {}
+    logits = hctr_ref.forward(state_dict, x, taps).numpy()
+    assert logits.shape == (max(widths), len(widths), synth.DEFAULT_VOCAB + 2)
+    sub = g["sub_classes"]
+    np.testing.assert_allclose(logits[:, :, sub], g[name + "/logits_sub"], atol=LOGIT_ATOL, rtol=0)
+    np.testing.assert_allclose(logits.max(axis=2), g[name + "/max"], atol=LOGIT_ATOL, rtol=0)
+    for k in ("stage0", "stage2", "stage4", "block3.4"):
+        np.testing.assert_allclose(taps[k][:, :8, :, :16].numpy(), g[name + "/act/" + k], atol=1e-4, rtol=0)
+    # indices: exact wherever the reference's own top-2 margin exceeds the float tolerance
+    margin = g[name + "/top10_val"][:, :, 0] - g[name + "/top10_val"][:, :, 1]
+    safe = margin > 4 * LOGIT_ATOL
+    assert safe.mean() > 0.99
+    assert np.array_equal(logits.argmax(axis=2)[safe], g[name + "/argmax"][safe].astype(np.int64))
+    codec = ctc_ref.CtcCodecRef(synth.characters())
+    if safe.all():
+        assert codec.decode(logits) == _strings()[name]["greedy"]
+
+
+def test_codec_cases_match_reference():
+    with open(os.path.join(GOLDEN, "codec_cases.json")) as f:
+        gold = json.load(f)
+    for name, seed, w, b, c, style in codec_cases.CODEC_CASES:
+        logits = codec_cases.gen_logits(seed, w, b, c, style)
+        chars = codec_cases.vocab(c)
+        codec = ctc_ref.CtcCodecRef(chars)
+        assert codec.decode(logits) == gold[name]["greedy"], name
+        enc = codec.encode(["".join(chars[:3]) + "?", "", chars[-1]])
+        assert [enc[0].tolist(), enc[1].tolist()] == gold[name]["encode"]
+        for tag, skip, lm, lp, lb, bs, depth in codec_cases.BEAM_SETTINGS:
+            codec = ctc_ref.CtcCodecRef(chars)
+            codec.use_beam_search, codec.skip_search = True, skip
+            codec.use_tfm_pred = False
+            codec.lm_panelty, codec.len_bonus, codec.beam_size, codec.search_depth = lp, lb, bs, depth
+            codec.ngram = ctc_ref.ZeroLM() if lm == "zero" else ctc_ref.ToyBigramLM()
+            try:
+                got = codec.decode(logits)
+            except IndexError:
+                got = "IndexError"
+            assert got == gold[name][tag], (name, tag)
+
+
+def test_codec_greedy_rules():
+    """Collapse rules of utils/ctc_codec.py:89-93, spelled out."""
+    codec = ctc_ref.CtcCodecRef("AB")            # C = 4: blank, A, B, unknown
+    def lg(seq):
+        x = np.zeros((len(seq), 1, 4), np.float32)
+        for t, s in enumerate(seq):
+            x[t, 0, s] = 1.0
+        return x
+    assert codec.decode(lg([1, 1, 2])) == ["AB"]
+    assert codec.decode(lg([1, 0, 1])) == ["AA"]          # blank separates repeats
+    assert codec.decode(lg([1, 3, 1])) == ["AA"]          # unknown is dropped but still separates
+    assert codec.decode(lg([0, 0, 3])) == [""]
+    assert codec.decode(np.zeros((3, 1, 4), np.float32)) == [""]   # ties -> first index (blank)
+    assert codec.decode(np.zeros((0, 2, 4), np.float32)) == []     # zero-length lines are skipped
+
+
+def test_edit_distance():
+    assert ctc_ref.edit_distance("kitten", "sitting") == 3
+    assert ctc_ref.edit_distance("", "abc") == 3
+    assert ctc_ref.edit_distance("abc", "abc") == 0
