@@ -1,0 +1,141 @@
+"""Build and bind libhctr_hip.so (the C ABI in include/hctr_hip.h) with ctypes.
+
+The shared library is built IN-TREE with hipcc for gfx950 (it travels to the GPU box with the
+snapshot). There is no fallback: if the library is missing or fails to load, importing callers get a
+loud error - the engine has no CPU path.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libhctr_hip.so")
+HEADER = os.path.join(ROOT, "include", "hctr_hip.h")
+
+# (source, extra flags). beam_search.cpp must not contract a*b+c (bit-parity with Python floats).
+SOURCES = [("kernels.hip", []), ("engine.cpp", ["-x", "hip"]), ("beam_search.cpp", ["-ffp-contract=off"])]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+HCTR_OK = 0
+ERR_ARG, ERR_HIP, ERR_STATE, ERR_KEY, ERR_SHAPE, ERR_EMPTY_LINE, ERR_NOMEM = -1, -2, -3, -4, -5, -6, -7
+U8, F32, I64 = 0, 1, 2
+
+
+def _stale():
+    if not os.path.isfile(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, "kernels.h"), HEADER]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/ into libhctr_hip.so (cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.isfile(hipcc):
+        hipcc = "hipcc"
+    objdir = os.path.join(PKG_DIR, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    for src, extra in SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-lpthread"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_LIB = None
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+
+LM_SCORE_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, c_i32p, c_i32p, c_f64p)
+LM_NEXT_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, c_i32p, c_i32p, ctypes.c_int, c_i32p)
+
+
+class BeamParams(ctypes.Structure):
+    _fields_ = [("skip_search", ctypes.c_int), ("beam_size", ctypes.c_int), ("search_depth", ctypes.c_int),
+                ("lm_panelty", ctypes.c_double), ("len_bonus", ctypes.c_double),
+                ("builtin_lm", ctypes.c_int), ("label_codepoints", ctypes.c_void_p),
+                ("score_cb", LM_SCORE_CB), ("next_cb", LM_NEXT_CB), ("user", ctypes.c_void_p),
+                ("num_threads", ctypes.c_int)]
+
+
+# every symbol include/hctr_hip.h declares: (name, restype, argtypes)
+_VP, _I, _I64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+SIGNATURES = [
+    ("hctr_create", _I, [ctypes.POINTER(_VP), _I, _I]),
+    ("hctr_destroy", None, [_VP]),
+    ("hctr_last_error", ctypes.c_char_p, [_VP]),
+    ("hctr_version", ctypes.c_char_p, []),
+    ("hctr_load_tensor", _I, [_VP, ctypes.c_char_p, _VP, c_i64p, _I, _I]),
+    ("hctr_finalize_weights", _I, [_VP]),
+    ("hctr_forward_logits", _I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I]),
+    ("hctr_greedy", _I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _VP]),
+    ("hctr_decode_greedy_logits", _I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP]),
+    ("hctr_beam_frontend", _I, [_VP, _VP, _I, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, c_i64p]),
+    ("hctr_beam_fetch_candidates", _I, [_VP, _VP, _VP, _VP]),
+    ("hctr_log_softmax", _I, [_VP, _VP, _I, _I, _I, _I, _VP]),
+    ("hctr_beam_search", _I, [ctypes.POINTER(BeamParams), _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
+                              _VP, _VP, _VP]),
+    ("hctr_set_profiling", _I, [_VP, _I]),
+    ("hctr_last_profile", _I, [_VP, ctypes.c_char_p, _I, c_f32p, _I]),
+    ("hctr_debug_activation", _I64, [_VP, ctypes.c_char_p, _VP, _I64, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+]
+
+
+def load():
+    """Load the library (building it first when the sources are newer). Raises on failure."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if _stale():
+        try:
+            build()
+        except (OSError, subprocess.CalledProcessError) as exc:
+            if not os.path.isfile(LIB_PATH):
+                raise RuntimeError("libhctr_hip.so is missing and could not be built with hipcc (%s); "
+                                   "the hctr engine has no CPU fallback" % exc)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, res, args in SIGNATURES:
+        fn = getattr(lib, name)          # AttributeError if the ABI drifted from the header
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+_EXC = {ERR_ARG: ValueError, ERR_HIP: RuntimeError, ERR_STATE: RuntimeError, ERR_KEY: KeyError,
+        ERR_SHAPE: RuntimeError, ERR_EMPTY_LINE: IndexError, ERR_NOMEM: MemoryError}
+
+
+def check(rc, ctx=None):
+    """Turn a negative hctr_status into the exception type the reference would raise."""
+    if rc == HCTR_OK:
+        return
+    msg = load().hctr_last_error(ctx)
+    msg = msg.decode("utf-8", "replace") if msg else ""
+    raise _EXC.get(rc, RuntimeError)("hctr engine error %d: %s" % (rc, msg))
+
+
+def ptr(a):
+    """ctypes void* of a numpy array / torch tensor / None."""
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return ctypes.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(ctypes.c_void_p)

@@ -1,0 +1,942 @@
+// libhctr_hip.so - host side of the MI355X hctr engine: context, checkpoint ingest (BatchNorm
+// folding + repack to kernel layouts), workspace, forward orchestration, and the C ABI declared in
+// include/hctr_hip.h. Reference citations are relative to the reference repository root.
+#include "../../include/hctr_hip.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace hctr;
+
+namespace {
+
+constexpr int kImgH = 128;                       // hctr_model.img_height, models/handwritten_ctr_model.py:159
+constexpr int kFeat = 2048;                      // 512 channels x 4 rows, :168-169
+constexpr double kBnEps = 1e-5;                  // nn.BatchNorm2d default
+constexpr int kStagePlanes[4] = {128, 256, 512, 512};
+constexpr int kStageBlocks[4] = {2, 4, 5, 1};    // ResNet(1, 512, BasicBlock, [2,4,5,1]), :166
+constexpr int kStageH[5] = {128, 64, 32, 16, 8}; // rows entering stage s (stage 0 = stem)
+constexpr int64_t kDefaultMaxCols = 131072;      // pixel columns (B*W) per internal pass
+
+std::string g_create_error;
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    mutable bool used = false;
+};
+
+struct ConvW {
+    half_t* w = nullptr;    // [taps][coutPad][cin] fp16, MFMA row order
+    float* bias = nullptr;  // [coutPad]
+    int cin = 0, cout = 0, coutPad = 0, taps = 0;
+};
+
+struct SeW {
+    float* w1 = nullptr;    // [c/16][c]
+    float* w2 = nullptr;    // [c][c/16]
+    int c = 0;
+};
+
+struct BlockW {
+    ConvW conv1, conv2, ds;
+    SeW se;
+    bool has_ds = false;
+};
+
+struct Workspace {
+    int B = 0, W = 0, Wa = 0;
+    void* img = nullptr;            // staged input (u8 or f32)
+    int32_t* widths = nullptr;
+    half_t* s0 = nullptr;           // conv0_1 output [B][130][Wa][64]
+    half_t* x[5] = {};              // x[s]: input of stage s (s = 1..4), padded NHWC
+    half_t* p[5][3] = {};           // rotating block buffers of stage s
+    half_t* headin = nullptr;       // [B*W][2048], k = h*512 + c
+    float* logits = nullptr;        // [B*W][Cpad]
+    float* se_part = nullptr;
+    float* se_scale = nullptr;
+    int32_t* colidx = nullptr;      // [B*W]
+    int32_t* labels = nullptr;      // [B][W]
+    int32_t* lengths = nullptr;     // [B]
+    std::vector<void*> allocs;
+    size_t bytes = 0;
+};
+
+struct ProfEntry {
+    std::string name;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct hctr_ctx {
+    int device = 0;
+    int num_classes = 0;
+    int cpad = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::map<std::string, HostTensor> host;
+    bool finalized = false;
+    // device weights
+    float* stem_w = nullptr;
+    float* stem_b = nullptr;
+    ConvW conv0_2;
+    std::vector<BlockW> blocks[4];
+    ConvW stage_conv[4];
+    ConvW head;
+    std::vector<void*> wallocs;
+    Workspace ws;
+    int64_t max_cols = kDefaultMaxCols;
+    // profiling
+    bool profiling = false;
+    std::vector<ProfEntry> prof;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    // beam front-end scratch + the candidate lists of the last hctr_beam_frontend call
+    std::vector<void*> beam_allocs;
+    std::vector<int64_t> cand_off;
+    std::vector<int32_t> cand_idx;
+    std::vector<float> cand_logp;
+};
+
+namespace {
+
+int fail(hctr_ctx* c, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(ctx, HCTR_ERR_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,          \
+                        hipGetErrorString(_e));                                                   \
+    } while (0)
+
+#define TRY(expr)                   \
+    do {                            \
+        int _r = (expr);            \
+        if (_r != HCTR_OK) return _r; \
+    } while (0)
+
+template <typename T>
+int dev_alloc(hctr_ctx* c, std::vector<void*>& pool, T** out, size_t count, bool zero, size_t* acct = nullptr) {
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess)
+        return fail(c, HCTR_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    pool.push_back(p);
+    if (acct) *acct += bytes;
+    if (zero) HIP_TRY(c, hipMemsetAsync(p, 0, bytes, c->stream));
+    *out = (T*)p;
+    return HCTR_OK;
+}
+
+void free_pool(std::vector<void*>& pool) {
+    for (void* p : pool) (void)hipFree(p);
+    pool.clear();
+}
+
+// ---------------------------------------------------------------------------------------------
+// checkpoint ingest
+// ---------------------------------------------------------------------------------------------
+const HostTensor* find(hctr_ctx* c, const std::string& key) {
+    auto it = c->host.find(key);
+    return it == c->host.end() ? nullptr : &it->second;
+}
+
+int need(hctr_ctx* c, const std::string& key, std::vector<int64_t> shape, const HostTensor** out) {
+    const HostTensor* t = find(c, key);
+    if (!t) return fail(c, HCTR_ERR_KEY, "Missing key(s) in state_dict: \"%s\"", key.c_str());
+    if (t->shape != shape) {
+        std::string got, want;
+        for (auto v : t->shape) got += std::to_string(v) + ",";
+        for (auto v : shape) want += std::to_string(v) + ",";
+        return fail(c, HCTR_ERR_SHAPE, "size mismatch for %s: checkpoint [%s] vs model [%s]", key.c_str(),
+                    got.c_str(), want.c_str());
+    }
+    t->used = true;
+    *out = t;
+    return HCTR_OK;
+}
+
+// stored row s of a 64-row block holds cout perm64(s): MFMA tile j = s/16, row ra = s%16 of that
+// tile is cout (ra>>2)*16 + j*4 + (ra&3), so an accumulator lane owns 16 consecutive couts.
+inline int perm64(int s) {
+    const int j = s >> 4, ra = s & 15;
+    return (ra >> 2) * 16 + j * 4 + (ra & 3);
+}
+
+// Conv2d + eval BatchNorm2d folded: w' = w * g/sqrt(v+eps), b' = (b - mean) * g/sqrt(v+eps) + beta
+// (models/handwritten_ctr_model.py:37-40, 73-92, 104-108). Folded in float64, stored fp16 / fp32.
+int build_conv(hctr_ctx* c, const std::string& ck, const std::string& bk, int cin, int cout, int ks,
+               bool has_bias, int pad_to, ConvW* out) {
+    const HostTensor *w, *b = nullptr, *g, *beta, *mean, *var;
+    TRY(need(c, ck + ".weight", {cout, cin, ks, ks}, &w));
+    if (has_bias) TRY(need(c, ck + ".bias", {cout}, &b));
+    TRY(need(c, bk + ".weight", {cout}, &g));
+    TRY(need(c, bk + ".bias", {cout}, &beta));
+    TRY(need(c, bk + ".running_mean", {cout}, &mean));
+    TRY(need(c, bk + ".running_var", {cout}, &var));
+    const int taps = ks * ks;
+    const int coutPad = (cout + pad_to - 1) / pad_to * pad_to;
+    std::vector<half_t> hw((size_t)taps * coutPad * cin, (half_t)0.f);
+    std::vector<float> hb(coutPad, 0.f);
+    for (int blk = 0; blk < coutPad / 64; ++blk)
+        for (int s = 0; s < 64; ++s) {
+            const int co = blk * 64 + perm64(s);
+            if (co >= cout) continue;
+            const double sc = (double)g->data[co] / std::sqrt((double)var->data[co] + kBnEps);
+            for (int t = 0; t < taps; ++t)
+                for (int ci = 0; ci < cin; ++ci) {
+                    const double v = (double)w->data[((size_t)co * cin + ci) * taps + t] * sc;
+                    hw[((size_t)t * coutPad + blk * 64 + s) * cin + ci] = (half_t)(float)v;
+                }
+        }
+    for (int co = 0; co < cout; ++co) {
+        const double sc = (double)g->data[co] / std::sqrt((double)var->data[co] + kBnEps);
+        const double bb = has_bias ? (double)b->data[co] : 0.0;
+        hb[co] = (float)((bb - (double)mean->data[co]) * sc + (double)beta->data[co]);
+    }
+    out->cin = cin; out->cout = cout; out->coutPad = coutPad; out->taps = taps;
+    TRY(dev_alloc(c, c->wallocs, &out->w, hw.size(), false));
+    TRY(dev_alloc(c, c->wallocs, &out->bias, hb.size(), false));
+    HIP_TRY(c, hipMemcpyAsync(out->w, hw.data(), hw.size() * sizeof(half_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out->bias, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // host vectors die at scope exit
+    return HCTR_OK;
+}
+
+int build_se(hctr_ctx* c, const std::string& key, int ch, SeW* out) {
+    const HostTensor *w1, *w2;
+    TRY(need(c, key + ".fc.0.weight", {ch / 16, ch}, &w1));
+    TRY(need(c, key + ".fc.2.weight", {ch, ch / 16}, &w2));
+    out->c = ch;
+    TRY(dev_alloc(c, c->wallocs, &out->w1, w1->data.size(), false));
+    TRY(dev_alloc(c, c->wallocs, &out->w2, w2->data.size(), false));
+    HIP_TRY(c, hipMemcpyAsync(out->w1, w1->data.data(), w1->data.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out->w2, w2->data.data(), w2->data.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HCTR_OK;
+}
+
+int build_stem(hctr_ctx* c) {
+    const HostTensor *w, *b, *g, *beta, *mean, *var;
+    TRY(need(c, "cnn.conv0_1.weight", {64, 1, 3, 3}, &w));
+    TRY(need(c, "cnn.conv0_1.bias", {64}, &b));
+    TRY(need(c, "cnn.bn0_1.weight", {64}, &g));
+    TRY(need(c, "cnn.bn0_1.bias", {64}, &beta));
+    TRY(need(c, "cnn.bn0_1.running_mean", {64}, &mean));
+    TRY(need(c, "cnn.bn0_1.running_var", {64}, &var));
+    std::vector<float> hw(64 * 9), hb(64);
+    for (int co = 0; co < 64; ++co) {
+        const double sc = (double)g->data[co] / std::sqrt((double)var->data[co] + kBnEps);
+        for (int t = 0; t < 9; ++t) hw[co * 9 + t] = (float)((double)w->data[co * 9 + t] * sc);
+        hb[co] = (float)(((double)b->data[co] - (double)mean->data[co]) * sc + (double)beta->data[co]);
+    }
+    TRY(dev_alloc(c, c->wallocs, &c->stem_w, hw.size(), false));
+    TRY(dev_alloc(c, c->wallocs, &c->stem_b, hb.size(), false));
+    HIP_TRY(c, hipMemcpyAsync(c->stem_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->stem_b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HCTR_OK;
+}
+
+// self.linear (models/handwritten_ctr_model.py:169,175). The reference's feature index is
+// d = c*4 + h (flatten(1,2) of [B,C,H,W], :173); the engine's head input is [pixel][h*512 + c].
+int build_head(hctr_ctx* c) {
+    const HostTensor *w, *b;
+    const int C = c->num_classes;
+    TRY(need(c, "linear.weight", {C, kFeat}, &w));
+    TRY(need(c, "linear.bias", {C}, &b));
+    const int cpad = c->cpad;
+    std::vector<half_t> hw((size_t)cpad * kFeat, (half_t)0.f);
+    std::vector<float> hb(cpad, 0.f);
+    for (int blk = 0; blk < cpad / 64; ++blk)
+        for (int s = 0; s < 64; ++s) {
+            const int n = blk * 64 + perm64(s);
+            if (n >= C) continue;
+            half_t* dst = &hw[(size_t)(blk * 64 + s) * kFeat];
+            const float* src = &w->data[(size_t)n * kFeat];
+            for (int ch = 0; ch < 512; ++ch)
+                for (int h = 0; h < 4; ++h) dst[h * 512 + ch] = (half_t)src[ch * 4 + h];
+        }
+    for (int n = 0; n < C; ++n) hb[n] = b->data[n];
+    c->head.cin = kFeat; c->head.cout = C; c->head.coutPad = cpad; c->head.taps = 1;
+    TRY(dev_alloc(c, c->wallocs, &c->head.w, hw.size(), false));
+    TRY(dev_alloc(c, c->wallocs, &c->head.bias, hb.size(), false));
+    HIP_TRY(c, hipMemcpyAsync(c->head.w, hw.data(), hw.size() * sizeof(half_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->head.bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HCTR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace: padded NHWC fp16 activations, one set of buffers per stage (borders stay zero)
+// ---------------------------------------------------------------------------------------------
+inline int64_t act_elems(int B, int H, int Wa, int C) { return (int64_t)B * (H + 2) * Wa * C; }
+
+int ensure_workspace(hctr_ctx* c, int B, int W) {
+    Workspace& ws = c->ws;
+    if (ws.B == B && ws.W == W) return HCTR_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_pool(ws.allocs);
+    ws = Workspace();
+    ws.B = B; ws.W = W;
+    const int tilesW = (W + kTileW - 1) / kTileW;
+    const int Wa = tilesW * kTileW + 2;
+    ws.Wa = Wa;
+    const int64_t cols = (int64_t)B * W;
+    TRY(dev_alloc(c, ws.allocs, (char**)&ws.img, (size_t)cols * kImgH * 4, false, &ws.bytes));
+    TRY(dev_alloc(c, ws.allocs, &ws.widths, (size_t)B, false, &ws.bytes));
+    TRY(dev_alloc(c, ws.allocs, &ws.s0, (size_t)act_elems(B, 128, Wa, 64), true, &ws.bytes));
+    int cin = 64;
+    size_t se_max = 0;
+    for (int s = 1; s <= 4; ++s) {
+        const int H = kStageH[s], planes = kStagePlanes[s - 1];
+        TRY(dev_alloc(c, ws.allocs, &ws.x[s], (size_t)act_elems(B, H, Wa, cin), true, &ws.bytes));
+        const int nbuf = (s == 4) ? 2 : 3;
+        for (int i = 0; i < nbuf; ++i)
+            TRY(dev_alloc(c, ws.allocs, &ws.p[s][i], (size_t)act_elems(B, H, Wa, planes), true, &ws.bytes));
+        se_max = std::max(se_max, (size_t)B * (H / 8) * tilesW * planes);
+        cin = planes;
+    }
+    TRY(dev_alloc(c, ws.allocs, &ws.headin, (size_t)cols * kFeat, false, &ws.bytes));
+    TRY(dev_alloc(c, ws.allocs, &ws.logits, (size_t)cols * c->cpad, false, &ws.bytes));
+    TRY(dev_alloc(c, ws.allocs, &ws.se_part, se_max, false, &ws.bytes));
+    TRY(dev_alloc(c, ws.allocs, &ws.se_scale, (size_t)B * 512, false, &ws.bytes));
+    TRY(dev_alloc(c, ws.allocs, &ws.colidx, (size_t)cols, false, &ws.bytes));
+    TRY(dev_alloc(c, ws.allocs, &ws.labels, (size_t)cols, false, &ws.bytes));
+    TRY(dev_alloc(c, ws.allocs, &ws.lengths, (size_t)B, false, &ws.bytes));
+    return HCTR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward orchestration
+// ---------------------------------------------------------------------------------------------
+struct Prof {
+    hctr_ctx* c;
+    bool on;
+    explicit Prof(hctr_ctx* ctx) : c(ctx), on(ctx->profiling) {}
+    hipEvent_t ev() {
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            c->ev_pool.push_back(e);
+        }
+        return c->ev_pool[c->ev_used++];
+    }
+    void begin(const char* name) {
+        if (!on) return;
+        ProfEntry pe{name, ev(), ev()};
+        (void)hipEventRecord(pe.e0, c->stream);
+        c->prof.push_back(pe);
+    }
+    void end() {
+        if (!on) return;
+        (void)hipEventRecord(c->prof.back().e1, c->stream);
+    }
+};
+
+struct ActDesc {            // a padded NHWC activation
+    half_t* p;
+    int H, C;
+};
+
+int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc in, half_t* out, int outH,
+             bool relu, bool pool, float* se_part, bool to_head) {
+    const Workspace& ws = c->ws;
+    ConvArgs a{};
+    a.x = in.p; a.w = cw.w; a.bias = cw.bias; a.y = out; a.se_part = se_part;
+    a.H = in.H; a.W = ws.W; a.Cin = cw.cin; a.Cout = cw.cout; a.CoutPad = cw.coutPad;
+    const ConvTile tile = cw.cout == 64 ? TILE_64x256 : TILE_128x128;
+    const int rows = tile == TILE_64x256 ? 16 : 8;
+    if (in.H % rows != 0 || cw.cin % kBK != 0)
+        return fail(c, HCTR_ERR_ARG, "conv %s: H=%d or Cin=%d not tileable", name, in.H, cw.cin);
+    a.tilesW = (ws.W + kTileW - 1) / kTileW;
+    a.tilesH = in.H / rows;
+    a.in_sb = (int64_t)(in.H + 2) * ws.Wa * cw.cin;
+    a.in_sh = ws.Wa * cw.cin;
+    if (to_head) {            // conv4 + pool -> head input [B][W][4][512]
+        a.out_sb = (int64_t)ws.W * kFeat; a.out_sh = 512; a.out_sw = kFeat; a.out_off = 0;
+        a.out_wlimit = ws.W;
+    } else {
+        a.out_sb = (int64_t)(outH + 2) * ws.Wa * cw.cout;
+        a.out_sh = ws.Wa * cw.cout; a.out_sw = cw.cout;
+        a.out_off = (int64_t)(ws.Wa + 1) * cw.cout;
+        a.out_wlimit = a.tilesW * kTileW;
+    }
+    a.relu = relu; a.pool = pool;
+    a.mtiles = ws.B * a.tilesH * a.tilesW;
+    a.ntiles = cw.coutPad / (tile == TILE_64x256 ? 64 : 128);
+    pf.begin(name);
+    HIP_TRY(c, launch_conv(a, tile, cw.taps, false, c->stream));
+    pf.end();
+    return HCTR_OK;
+}
+
+// BasicBlock.forward (models/handwritten_ctr_model.py:47-60)
+int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, ActDesc in, half_t* t,
+              half_t* o, half_t* r, int planes) {
+    const Workspace& ws = c->ws;
+    const int H = in.H;
+    TRY(run_conv(c, pf, (name + ".conv1").c_str(), bw.conv1, in, t, H, true, false, nullptr, false));
+    TRY(run_conv(c, pf, (name + ".conv2").c_str(), bw.conv2, ActDesc{t, H, planes}, o, H, false, false,
+                 ws.se_part, false));
+    const int tiles = (H / 8) * ((ws.W + kTileW - 1) / kTileW);
+    pf.begin((name + ".se_fc").c_str());
+    HIP_TRY(c, launch_se_fc(ws.se_part, tiles, bw.se.w1, bw.se.w2, ws.se_scale, ws.B, planes,
+                            1.0f / ((float)H * (float)ws.W), c->stream));
+    pf.end();
+    const half_t* res = in.p;
+    if (bw.has_ds) {
+        TRY(run_conv(c, pf, (name + ".downsample").c_str(), bw.ds, in, r, H, false, false, nullptr, false));
+        res = r;
+    }
+    pf.begin((name + ".se_apply").c_str());
+    HIP_TRY(c, launch_se_apply(o, res, ws.se_scale, (int64_t)(H + 2) * ws.Wa * planes, ws.B, planes, c->stream));
+    pf.end();
+    return HCTR_OK;
+}
+
+// trunk + head for the staged batch in ws.img: leaves [B*W][cpad] fp32 logits in ws.logits.
+// ResNet.forward :115-153 and hctr_model.forward :171-176.
+int run_forward(hctr_ctx* c, int img_f32, bool have_widths) {
+    Workspace& ws = c->ws;
+    Prof pf(c);
+    if (c->profiling) { c->prof.clear(); c->ev_used = 0; }
+    pf.begin("stem.conv0_1");
+    HIP_TRY(c, launch_stem(ws.img, img_f32, have_widths ? ws.widths : nullptr, c->stem_w, c->stem_b, ws.s0, ws.B,
+                           ws.W, ws.Wa, c->stream));
+    pf.end();
+    TRY(run_conv(c, pf, "conv0_2+pool", c->conv0_2, ActDesc{ws.s0, 128, 64}, ws.x[1], 64, true, true, nullptr, false));
+    int cin = 64;
+    for (int s = 1; s <= 4; ++s) {
+        const int H = kStageH[s], planes = kStagePlanes[s - 1];
+        ActDesc cur{ws.x[s], H, cin};
+        int ci = -1;                              // index of the buffer holding `cur`; -1 = stage input
+        for (size_t i = 0; i < c->blocks[s - 1].size(); ++i) {
+            const BlockW& bw = c->blocks[s - 1][i];
+            char nm[48];
+            snprintf(nm, sizeof(nm), "block%d.%zu", s, i);
+            // three rotating buffers: t and o go to the two that do not hold the block input; the
+            // 1x1-downsample residual (first block of stages 1-3 only) uses the third.
+            const int ti = ci < 0 ? 0 : (ci + 1) % 3, oi = ci < 0 ? 1 : (ci + 2) % 3;
+            if (bw.has_ds && ci >= 0) return fail(c, HCTR_ERR_STATE, "downsample only expected on a stage's first block");
+            TRY(run_block(c, pf, nm, bw, cur, ws.p[s][ti], ws.p[s][oi], bw.has_ds ? ws.p[s][2] : nullptr, planes));
+            cur = ActDesc{ws.p[s][oi], H, planes};
+            ci = oi;
+        }
+        char nm[32];
+        snprintf(nm, sizeof(nm), "conv%d+pool", s);
+        if (s < 4)
+            TRY(run_conv(c, pf, nm, c->stage_conv[s - 1], cur, ws.x[s + 1], H / 2, true, true, nullptr, false));
+        else
+            TRY(run_conv(c, pf, nm, c->stage_conv[s - 1], cur, ws.headin, H / 2, true, true, nullptr, true));
+        cin = planes;
+    }
+    // head GEMM
+    ConvArgs a{};
+    a.x = ws.headin; a.w = c->head.w; a.bias = c->head.bias; a.y = ws.logits;
+    a.Cin = kFeat; a.Cout = c->num_classes; a.CoutPad = c->cpad;
+    a.M = (int64_t)ws.B * ws.W; a.ldo = c->cpad;
+    a.mtiles = (int)((a.M + 127) / 128); a.ntiles = c->cpad / 128;
+    pf.begin("head.linear");
+    HIP_TRY(c, launch_conv(a, TILE_128x128, 1, true, c->stream));
+    pf.end();
+    return HCTR_OK;
+}
+
+int stage_input(hctr_ctx* c, const void* img, int img_dtype, int img_on_device, const int32_t* widths, int b0,
+                int nb, int Bfull, int W) {
+    Workspace& ws = c->ws;
+    const size_t esz = img_dtype == HCTR_F32 ? 4 : 1;
+    const size_t per = (size_t)kImgH * W * esz;
+    const char* src = (const char*)img + (size_t)b0 * per;
+    HIP_TRY(c, hipMemcpyAsync(ws.img, src, per * nb, img_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                              c->stream));
+    if (widths) {
+        for (int i = 0; i < nb; ++i)
+            if (widths[b0 + i] < 1 || widths[b0 + i] > W)
+                return fail(c, HCTR_ERR_ARG, "widths[%d]=%d outside [1,%d]", b0 + i, widths[b0 + i], W);
+        HIP_TRY(c, hipMemcpyAsync(ws.widths, widths + b0, (size_t)nb * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    (void)Bfull;
+    return HCTR_OK;
+}
+
+int check_forward_args(hctr_ctx* c, const void* img, int img_dtype, int B, int W) {
+    if (!c) return HCTR_ERR_ARG;
+    if (!c->finalized) return fail(c, HCTR_ERR_STATE, "weights not finalized: call hctr_finalize_weights first");
+    if (!img) return fail(c, HCTR_ERR_ARG, "img is NULL");
+    if (img_dtype != HCTR_U8 && img_dtype != HCTR_F32) return fail(c, HCTR_ERR_ARG, "img_dtype must be U8 or F32");
+    if (B < 0 || W < 1) return fail(c, HCTR_ERR_ARG, "bad batch shape B=%d W=%d", B, W);
+    return HCTR_OK;
+}
+
+int sub_batch(hctr_ctx* c, int B, int W) {
+    int64_t nb = c->max_cols / W;
+    if (nb < 1) nb = 1;
+    return (int)std::min<int64_t>(nb, B);
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char* hctr_version(void) { return "hctr-hip 0.1 (gfx950, f16 storage / f16 MFMA / f32 accumulate)"; }
+
+int hctr_create(hctr_ctx** out, int device, int num_classes) {
+    if (!out) return fail(nullptr, HCTR_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (num_classes < 3) return fail(nullptr, HCTR_ERR_ARG, "num_classes must be >= 3 (blank + chars + unknown)");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, HCTR_ERR_HIP, "no HIP device available (%s): the hctr engine has no CPU fallback",
+                    hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, HCTR_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, HCTR_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    hctr_ctx* c = new hctr_ctx();
+    c->device = device;
+    c->num_classes = num_classes;
+    c->cpad = (num_classes + 127) / 128 * 128;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(nullptr, HCTR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    if (const char* mc = getenv("HCTR_MAX_COLS")) {
+        const long long v = atoll(mc);
+        if (v > 0) c->max_cols = v;
+    }
+    *out = c;
+    return HCTR_OK;
+}
+
+void hctr_destroy(hctr_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_pool(c->ws.allocs);
+    free_pool(c->wallocs);
+    free_pool(c->beam_allocs);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* hctr_last_error(const hctr_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int hctr_load_tensor(hctr_ctx* c, const char* key, const void* host_ptr, const int64_t* shape, int ndim, int dtype) {
+    if (!c) return HCTR_ERR_ARG;
+    if (!key || (!host_ptr && ndim > 0) || ndim < 0 || ndim > 8) return fail(c, HCTR_ERR_ARG, "bad tensor arguments");
+    if (c->finalized) return fail(c, HCTR_ERR_STATE, "weights already finalized");
+    const std::string k(key);
+    if (dtype == HCTR_I64) {       // num_batches_tracked: accepted, unused in eval mode
+        if (k.size() < 19 || k.compare(k.size() - 19, 19, "num_batches_tracked") != 0)
+            return fail(c, HCTR_ERR_KEY, "Unexpected key(s) in state_dict: \"%s\" (int64)", key);
+        return HCTR_OK;
+    }
+    if (dtype != HCTR_F32) return fail(c, HCTR_ERR_ARG, "tensor %s: only float32 parameters are supported", key);
+    HostTensor t;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 0) return fail(c, HCTR_ERR_ARG, "negative dimension");
+        t.shape.push_back(shape[i]);
+        n *= shape[i];
+    }
+    t.data.assign((const float*)host_ptr, (const float*)host_ptr + n);
+    c->host[k] = std::move(t);
+    return HCTR_OK;
+}
+
+int hctr_finalize_weights(hctr_ctx* c) {
+    if (!c) return HCTR_ERR_ARG;
+    if (c->finalized) return fail(c, HCTR_ERR_STATE, "weights already finalized");
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(build_stem(c));
+    TRY(build_conv(c, "cnn.conv0_2", "cnn.bn0_2", 64, 64, 3, true, 64, &c->conv0_2));
+    int inpl = 64;
+    for (int s = 0; s < 4; ++s) {
+        const int planes = kStagePlanes[s];
+        c->blocks[s].resize(kStageBlocks[s]);
+        for (int i = 0; i < kStageBlocks[s]; ++i) {
+            BlockW& bw = c->blocks[s][i];
+            const std::string p = "cnn.block" + std::to_string(s + 1) + "." + std::to_string(i);
+            if (i == 0 && inpl != planes) {
+                bw.has_ds = true;
+                TRY(build_conv(c, p + ".downsample.0", p + ".downsample.1", inpl, planes, 1, false, 128, &bw.ds));
+            }
+            TRY(build_conv(c, p + ".conv1", p + ".bn1", inpl, planes, 3, true, 128, &bw.conv1));
+            TRY(build_conv(c, p + ".conv2", p + ".bn2", planes, planes, 3, true, 128, &bw.conv2));
+            TRY(build_se(c, p + ".se", planes, &bw.se));
+            inpl = planes;
+        }
+        const std::string k = "cnn.conv" + std::to_string(s + 1);
+        TRY(build_conv(c, k, "cnn.bn" + std::to_string(s + 1), planes, planes, 3, true, 128, &c->stage_conv[s]));
+    }
+    TRY(build_head(c));
+    // strict load: no unexpected float keys (load_state_dict(strict=True), test.py:153)
+    for (auto& kv : c->host)
+        if (!kv.second.used)
+            return fail(c, HCTR_ERR_KEY, "Unexpected key(s) in state_dict: \"%s\"", kv.first.c_str());
+    c->host.clear();
+    c->finalized = true;
+    return HCTR_OK;
+}
+
+int hctr_set_profiling(hctr_ctx* c, int enabled) {
+    if (!c) return HCTR_ERR_ARG;
+    c->profiling = enabled != 0;
+    return HCTR_OK;
+}
+
+int hctr_last_profile(hctr_ctx* c, char* names_buf, int cap, float* ms, int max_n) {
+    if (!c) return HCTR_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::string names;
+    int n = 0;
+    for (auto& pe : c->prof) {
+        if (n >= max_n) break;
+        float t = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&t, pe.e0, pe.e1));
+        ms[n++] = t;
+        names += pe.name;
+        names += '\n';
+    }
+    if (names_buf && cap > 0) {
+        strncpy(names_buf, names.c_str(), (size_t)cap - 1);
+        names_buf[cap - 1] = 0;
+    }
+    return n;
+}
+
+int hctr_forward_logits(hctr_ctx* c, const void* img, int img_dtype, int img_on_device, const int32_t* widths,
+                        int B, int W, float* out_wbc, int out_on_device) {
+    TRY(check_forward_args(c, img, img_dtype, B, W));
+    if (!out_wbc) return fail(c, HCTR_ERR_ARG, "out_wbc is NULL");
+    if (B == 0) return HCTR_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int C = c->num_classes;
+    const int nbmax = sub_batch(c, B, W);
+    float* dev_out = out_wbc;
+    std::vector<void*> tmp;
+    if (!out_on_device) {
+        int r = dev_alloc(c, tmp, &dev_out, (size_t)B * W * C, false);
+        if (r != HCTR_OK) { free_pool(tmp); return r; }
+    }
+    int rc = HCTR_OK;
+    for (int b0 = 0; b0 < B && rc == HCTR_OK; b0 += nbmax) {
+        const int nb = std::min(nbmax, B - b0);
+        rc = ensure_workspace(c, nb, W);
+        if (rc == HCTR_OK) rc = stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W);
+        if (rc == HCTR_OK) rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr);
+        if (rc == HCTR_OK) {
+            // [nb*W][cpad] -> out[t][b0+b][C] with full-batch row stride
+            hipError_t e = launch_logits_to_wbc(c->ws.logits, c->cpad, nb, W, C, dev_out, B, b0, c->stream);
+            if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "logits_to_wbc: %s", hipGetErrorString(e));
+        }
+    }
+    if (rc == HCTR_OK && !out_on_device) {
+        hipError_t e = hipMemcpyAsync(out_wbc, dev_out, (size_t)B * W * C * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "D2H logits: %s", hipGetErrorString(e));
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
+    free_pool(tmp);
+    return rc;
+}
+
+int hctr_greedy(hctr_ctx* c, const void* img, int img_dtype, int img_on_device, const int32_t* widths, int B, int W,
+                int32_t* labels, int32_t* lengths) {
+    TRY(check_forward_args(c, img, img_dtype, B, W));
+    if (!labels || !lengths) return fail(c, HCTR_ERR_ARG, "labels/lengths is NULL");
+    if (B == 0) return HCTR_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int C = c->num_classes;
+    const int nbmax = sub_batch(c, B, W);
+    for (int b0 = 0; b0 < B; b0 += nbmax) {
+        const int nb = std::min(nbmax, B - b0);
+        TRY(ensure_workspace(c, nb, W));
+        TRY(stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W));
+        TRY(run_forward(c, img_dtype == HCTR_F32, widths != nullptr));
+        Workspace& ws = c->ws;
+        Prof pf(c);
+        pf.begin("argmax_rows");
+        HIP_TRY(c, launch_argmax_rows(ws.logits, c->cpad, (int64_t)nb * W, C, ws.colidx, 0, 0, c->stream));
+        pf.end();
+        pf.begin("ctc_collapse");
+        HIP_TRY(c, launch_ctc_collapse(ws.colidx, nb, W, C, ws.labels, ws.lengths, c->stream));
+        pf.end();
+        HIP_TRY(c, hipMemcpyAsync(labels + (size_t)b0 * W, ws.labels, (size_t)nb * W * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(lengths + b0, ws.lengths, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return HCTR_OK;
+}
+
+int hctr_decode_greedy_logits(hctr_ctx* c, const float* logits_wbc, int on_device, int W, int B, int C,
+                              int32_t* labels, int32_t* lengths) {
+    if (!c) return HCTR_ERR_ARG;
+    if (W < 0 || B < 0 || C < 2) return fail(c, HCTR_ERR_ARG, "bad logits shape W=%d B=%d C=%d", W, B, C);
+    if ((int64_t)W * B == 0) return HCTR_OK;     // reference: zero-length lines produce no output (:85-86)
+    if (!logits_wbc || !labels || !lengths) return fail(c, HCTR_ERR_ARG, "NULL pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<void*> tmp;
+    const size_t n = (size_t)W * B * C;
+    const float* dev = logits_wbc;
+    float* up = nullptr;
+    int32_t *idx = nullptr, *dl = nullptr, *dn = nullptr;
+    int rc = HCTR_OK;
+    if (!on_device) {
+        rc = dev_alloc(c, tmp, &up, n, false);
+        if (rc == HCTR_OK) {
+            hipError_t e = hipMemcpyAsync(up, logits_wbc, n * 4, hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "H2D logits: %s", hipGetErrorString(e));
+        }
+        dev = up;
+    }
+    if (rc == HCTR_OK) rc = dev_alloc(c, tmp, &idx, (size_t)W * B, false);
+    if (rc == HCTR_OK) rc = dev_alloc(c, tmp, &dl, (size_t)W * B, false);
+    if (rc == HCTR_OK) rc = dev_alloc(c, tmp, &dn, (size_t)B, false);
+    if (rc == HCTR_OK) {
+        // rows of the WBC tensor are r = t*B + b; the argmax kernel writes idx as [b][t]
+        hipError_t e = launch_argmax_rows(dev, C, (int64_t)W * B, C, idx, B, W, c->stream);
+        if (e == hipSuccess) e = launch_ctc_collapse(idx, B, W, C, dl, dn, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(labels, dl, (size_t)W * B * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(lengths, dn, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "decode_greedy_logits: %s", hipGetErrorString(e));
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
+    free_pool(tmp);
+    return rc;
+}
+
+int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_device, const int32_t* widths,
+                       const float* logits_wbc, int logits_on_device, int B, int W, int C, int k,
+                       int want_candidates, int32_t* topk_idx, float* topk_logp, float* blank_logp,
+                       int64_t* num_candidates) {
+    if (!c) return HCTR_ERR_ARG;
+    if (B < 0 || W < 0 || k < 1) return fail(c, HCTR_ERR_ARG, "bad shape B=%d W=%d k=%d", B, W, k);
+    if (!topk_idx || !topk_logp || !blank_logp) return fail(c, HCTR_ERR_ARG, "NULL output pointer");
+    c->cand_off.assign((size_t)W * B + 1, 0);
+    c->cand_idx.clear();
+    c->cand_logp.clear();
+    if (num_candidates) *num_candidates = 0;
+    if ((int64_t)B * W == 0) return HCTR_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bool from_img = img != nullptr;
+    if (from_img) {
+        TRY(check_forward_args(c, img, img_dtype, B, W));
+        if (C != c->num_classes) return fail(c, HCTR_ERR_ARG, "C=%d differs from the model's %d classes", C, c->num_classes);
+    } else if (!logits_wbc) {
+        return fail(c, HCTR_ERR_ARG, "neither img nor logits given");
+    }
+    if (k > C) return fail(c, HCTR_ERR_ARG, "k=%d exceeds C=%d", k, C);
+    const double thresh = std::log(0.001);        // utils/ctc_codec.py:128
+    const int nbmax = from_img ? sub_batch(c, B, W) : B;
+    struct PassOut { int b0, nb; std::vector<int64_t> loff; std::vector<int32_t> ci; std::vector<float> cl; };
+    std::vector<PassOut> outs;
+    std::vector<int32_t> counts((size_t)W * B, 0);
+    std::vector<int32_t> h_idx, h_cnt;
+    std::vector<float> h_lp, h_bl;
+    std::vector<void*>& pool = c->beam_allocs;
+    int rc = HCTR_OK;
+    for (int b0 = 0; b0 < B && rc == HCTR_OK; b0 += nbmax) {
+        const int nb = std::min(nbmax, B - b0);
+        const int64_t rows = (int64_t)nb * W;
+        free_pool(pool);
+        const float* rowsrc = nullptr;
+        int64_t ld = 0;
+        if (from_img) {
+            rc = ensure_workspace(c, nb, W);
+            if (rc == HCTR_OK) rc = stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W);
+            if (rc == HCTR_OK) rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr);
+            rowsrc = c->ws.logits; ld = c->cpad;
+        } else {
+            float *up = nullptr, *rowsbuf = nullptr;
+            const float* dev = logits_wbc;
+            if (!logits_on_device) {
+                rc = dev_alloc(c, pool, &up, (size_t)rows * C, false);
+                if (rc == HCTR_OK) {
+                    hipError_t e = hipMemcpyAsync(up, logits_wbc, (size_t)rows * C * 4, hipMemcpyHostToDevice, c->stream);
+                    if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "H2D logits: %s", hipGetErrorString(e));
+                }
+                dev = up;
+            }
+            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &rowsbuf, (size_t)rows * C, false);
+            if (rc == HCTR_OK) {
+                hipError_t e = launch_wbc_to_rows(dev, nb, W, C, rowsbuf, C, c->stream);
+                if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "wbc_to_rows: %s", hipGetErrorString(e));
+            }
+            rowsrc = rowsbuf; ld = C;
+        }
+        int32_t *d_idx = nullptr, *d_cnt = nullptr;
+        float *d_lp = nullptr, *d_bl = nullptr, *d_st = nullptr;
+        if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_idx, (size_t)rows * k, false);
+        if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_lp, (size_t)rows * k, false);
+        if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_bl, (size_t)rows, false);
+        if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_st, (size_t)rows * 2, false);
+        if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_cnt, (size_t)rows, false);
+        if (rc != HCTR_OK) break;
+        hipError_t e = launch_row_topk(rowsrc, ld, nb, W, C, k, thresh, d_idx, d_lp, d_bl, d_st, d_cnt, c->stream);
+        if (e != hipSuccess) { rc = fail(c, HCTR_ERR_HIP, "row_topk: %s (C=%d)", hipGetErrorString(e), C); break; }
+        h_idx.resize((size_t)rows * k); h_lp.resize((size_t)rows * k); h_bl.resize(rows); h_cnt.resize(rows);
+        e = hipMemcpyAsync(h_idx.data(), d_idx, (size_t)rows * k * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_lp.data(), d_lp, (size_t)rows * k * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_bl.data(), d_bl, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc = fail(c, HCTR_ERR_HIP, "beam D2H: %s", hipGetErrorString(e)); break; }
+        for (int t = 0; t < W; ++t)
+            for (int b = 0; b < nb; ++b) {
+                const size_t src = (size_t)t * nb + b, dst = (size_t)t * B + b0 + b;
+                memcpy(topk_idx + dst * k, h_idx.data() + src * k, (size_t)k * 4);
+                memcpy(topk_logp + dst * k, h_lp.data() + src * k, (size_t)k * 4);
+                blank_logp[dst] = h_bl[src];
+                counts[dst] = h_cnt[src];
+            }
+        if (!want_candidates) continue;
+        outs.emplace_back();
+        PassOut& po = outs.back();
+        po.b0 = b0; po.nb = nb;
+        po.loff.resize(rows + 1);
+        int64_t tot = 0;
+        for (int64_t r = 0; r < rows; ++r) { po.loff[r] = tot; tot += h_cnt[r]; }
+        po.loff[rows] = tot;
+        po.ci.resize(tot); po.cl.resize(tot);
+        int64_t* d_off = nullptr;
+        int32_t* d_ci = nullptr;
+        float* d_cl = nullptr;
+        rc = dev_alloc(c, pool, &d_off, (size_t)rows + 1, false);
+        if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_ci, (size_t)std::max<int64_t>(tot, 1), false);
+        if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_cl, (size_t)std::max<int64_t>(tot, 1), false);
+        if (rc != HCTR_OK) break;
+        e = hipMemcpyAsync(d_off, po.loff.data(), (size_t)(rows + 1) * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = launch_row_candidates(rowsrc, ld, nb, W, C, thresh, d_st, d_off, d_ci, d_cl, c->stream);
+        if (e == hipSuccess && tot) e = hipMemcpyAsync(po.ci.data(), d_ci, (size_t)tot * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && tot) e = hipMemcpyAsync(po.cl.data(), d_cl, (size_t)tot * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc = fail(c, HCTR_ERR_HIP, "row_candidates: %s", hipGetErrorString(e)); break; }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    free_pool(pool);
+    if (rc != HCTR_OK || !want_candidates) return rc;
+    // merge the per-pass lists into one CSR in (t*B + b) order, held by the context until fetched
+    int64_t tot = 0;
+    for (int64_t r = 0; r < (int64_t)W * B; ++r) { c->cand_off[r] = tot; tot += counts[r]; }
+    c->cand_off[(size_t)W * B] = tot;
+    c->cand_idx.resize(tot); c->cand_logp.resize(tot);
+    for (const PassOut& po : outs)
+        for (int t = 0; t < W; ++t)
+            for (int b = 0; b < po.nb; ++b) {
+                const size_t src = (size_t)t * po.nb + b, dst = (size_t)t * B + po.b0 + b;
+                const int64_t n = po.loff[src + 1] - po.loff[src];
+                if (n) {
+                    memcpy(c->cand_idx.data() + c->cand_off[dst], po.ci.data() + po.loff[src], (size_t)n * 4);
+                    memcpy(c->cand_logp.data() + c->cand_off[dst], po.cl.data() + po.loff[src], (size_t)n * 4);
+                }
+            }
+    if (num_candidates) *num_candidates = tot;
+    return HCTR_OK;
+}
+
+int hctr_beam_fetch_candidates(hctr_ctx* c, int64_t* cand_off, int32_t* cand_idx, float* cand_logp) {
+    if (!c) return HCTR_ERR_ARG;
+    if (c->cand_off.empty()) return fail(c, HCTR_ERR_STATE, "no candidate lists: call hctr_beam_frontend(want_candidates=1)");
+    if (!cand_off) return fail(c, HCTR_ERR_ARG, "cand_off is NULL");
+    memcpy(cand_off, c->cand_off.data(), c->cand_off.size() * 8);
+    if (!c->cand_idx.empty()) {
+        if (!cand_idx || !cand_logp) return fail(c, HCTR_ERR_ARG, "cand_idx/cand_logp is NULL");
+        memcpy(cand_idx, c->cand_idx.data(), c->cand_idx.size() * 4);
+        memcpy(cand_logp, c->cand_logp.data(), c->cand_logp.size() * 4);
+    }
+    return HCTR_OK;
+}
+
+int hctr_log_softmax(hctr_ctx* c, const float* logits_wbc, int on_device, int W, int B, int C, float* out_host) {
+    if (!c) return HCTR_ERR_ARG;
+    if (W < 0 || B < 0 || C < 1) return fail(c, HCTR_ERR_ARG, "bad shape");
+    const int64_t rows = (int64_t)W * B;
+    if (rows == 0) return HCTR_OK;
+    if (!logits_wbc || !out_host) return fail(c, HCTR_ERR_ARG, "NULL pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<void*> tmp;
+    const float* dev = logits_wbc;
+    float *up = nullptr, *y = nullptr;
+    int rc = HCTR_OK;
+    if (!on_device) {
+        rc = dev_alloc(c, tmp, &up, (size_t)rows * C, false);
+        if (rc == HCTR_OK) {
+            hipError_t e = hipMemcpyAsync(up, logits_wbc, (size_t)rows * C * 4, hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "H2D logits: %s", hipGetErrorString(e));
+        }
+        dev = up;
+    }
+    if (rc == HCTR_OK) rc = dev_alloc(c, tmp, &y, (size_t)rows * C, false);
+    if (rc == HCTR_OK) {
+        hipError_t e = launch_log_softmax_rows(dev, rows, C, y, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_host, y, (size_t)rows * C * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "log_softmax: %s", hipGetErrorString(e));
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
+    free_pool(tmp);
+    return rc;
+}
+
+int64_t hctr_debug_activation(hctr_ctx* c, const char* name, float* out, int64_t cap, int* Cout, int* Hout) {
+    if (!c || !name) return HCTR_ERR_ARG;
+    const Workspace& ws = c->ws;
+    if (ws.B == 0) return fail(c, HCTR_ERR_STATE, "no forward has run");
+    const half_t* p = nullptr;
+    int H = 0, C = 0;
+    bool head = false;
+    const std::string n(name);
+    if (n == "conv0_1") { p = ws.s0; H = 128; C = 64; }
+    else if (n == "stage0") { p = ws.x[1]; H = 64; C = 64; }
+    else if (n == "stage1") { p = ws.x[2]; H = 32; C = 128; }
+    else if (n == "stage2") { p = ws.x[3]; H = 16; C = 256; }
+    else if (n == "stage3") { p = ws.x[4]; H = 8; C = 512; }
+    else if (n == "stage4") { p = ws.headin; H = 4; C = 512; head = true; }
+    else return fail(c, HCTR_ERR_ARG, "unknown activation '%s'", name);
+    const int64_t total = (int64_t)ws.B * C * H * ws.W;
+    if (Cout) *Cout = C;
+    if (Hout) *Hout = H;
+    if (!out || cap < total) return total;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int64_t elems = head ? (int64_t)ws.B * ws.W * kFeat : act_elems(ws.B, H, ws.Wa, C);
+    std::vector<half_t> host((size_t)elems);
+    HIP_TRY(c, hipMemcpy(host.data(), p, (size_t)elems * sizeof(half_t), hipMemcpyDeviceToHost));
+    for (int b = 0; b < ws.B; ++b)
+        for (int ch = 0; ch < C; ++ch)
+            for (int h = 0; h < H; ++h)
+                for (int w = 0; w < ws.W; ++w) {
+                    const int64_t src = head ? (((int64_t)b * ws.W + w) * 4 + h) * 512 + ch
+                                             : (((int64_t)b * (H + 2) + h + 1) * ws.Wa + w + 1) * C + ch;
+                    out[(((int64_t)b * C + ch) * H + h) * ws.W + w] = (float)host[(size_t)src];
+                }
+    return total;
+}
+
+}  // extern "C"

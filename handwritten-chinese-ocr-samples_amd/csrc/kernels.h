@@ -1,0 +1,79 @@
+// Launch interface between the engine (engine.cpp) and the gfx950 kernels (kernels.hip).
+// Internal to libhctr_hip.so; the public C ABI is include/hctr_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hctr {
+
+typedef _Float16 half_t;
+
+constexpr int kTileW = 16;      // output columns per pixel tile (all conv layers)
+constexpr int kBK = 64;         // input channels per k-step
+
+// One MFMA implicit-GEMM launch: 3x3 / 1x1 convolution over padded NHWC fp16 activations, or the
+// head projection (MODE linear). See DESIGN.md "conv_mfma" for the tiling.
+struct ConvArgs {
+    const half_t* x;        // input base: padded NHWC [B][H+2][Wa][Cin] (conv) or [M][Cin] (linear)
+    const half_t* w;        // [taps][CoutPad][Cin], rows permuted to MFMA order within 64-blocks
+    const float* bias;      // [CoutPad] folded BatchNorm bias
+    void* y;                // output base (fp16, or fp32 for the head)
+    float* se_part;         // [B][tilesH*tilesW][Cout] partial channel sums, or nullptr
+    int H, W;               // conv output rows / valid columns (pre-pool)
+    int Cin, Cout, CoutPad;
+    int tilesW, tilesH;     // pixel tiles per image
+    int64_t in_sb;          // input batch stride (elements)
+    int in_sh;              // input row stride (elements); pixel stride is Cin
+    int64_t out_sb;         // output batch stride (elements)
+    int out_sh, out_sw;     // output row / column strides (elements); row index is post-pool
+    int64_t out_off;        // element offset of output pixel (b=0,h=0,w=0)
+    int out_wlimit;         // columns [W, out_wlimit) are written as zeros (keeps the zero border)
+    int relu, pool;
+    int64_t M;              // linear mode: number of rows
+    int64_t ldo;            // linear mode: output leading dimension (elements)
+    int mtiles, ntiles;
+};
+
+// tile configurations: (couts x pixels) per 256-thread block
+enum ConvTile { TILE_64x256 = 0, TILE_128x128 = 1 };
+
+hipError_t launch_conv(const ConvArgs& a, ConvTile tile, int taps, bool linear_f32, hipStream_t s);
+size_t conv_lds_bytes(ConvTile tile);
+
+hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, const float* w9,
+                       const float* bias, half_t* y, int B, int W, int Wa, hipStream_t s);
+
+hipError_t launch_se_fc(const float* se_part, int tiles_per_img, const float* w1, const float* w2,
+                        float* scale, int B, int C, float inv_hw, hipStream_t s);
+
+hipError_t launch_se_apply(half_t* o, const half_t* r, const float* scale, int64_t img_elems,
+                           int B, int C, hipStream_t s);
+
+// tB > 0: rows are in WBC order (r = t*tB + b) and idx is written as [b][t] with row length tW
+hipError_t launch_argmax_rows(const float* logits, int64_t ld, int64_t M, int C, int32_t* idx,
+                              int tB, int tW, hipStream_t s);
+
+// raw per-column indices [B][W] (row m = b*W + t) -> collapsed labels [B][W] + lengths [B]
+hipError_t launch_ctc_collapse(const int32_t* idx, int B, int W, int C, int32_t* labels,
+                               int32_t* lengths, hipStream_t s);
+
+// sub-batch rows [B*W][ld] -> out[t][b0 + b][C] of a [W][Bfull][C] tensor
+hipError_t launch_logits_to_wbc(const float* logits, int64_t ld, int B, int W, int C, float* out,
+                                int Bfull, int b0, hipStream_t s);
+// [W][B][C] -> [B*W][ld] (for caller-supplied logits)
+hipError_t launch_wbc_to_rows(const float* wbc, int B, int W, int C, float* rows, int64_t ld,
+                              hipStream_t s);
+
+// log-softmax + top-k (+ count of candidates above thresh) per (t,b) row of [B*W][ld]; outputs are
+// indexed r = t*B + b. stats receives (row max, log-sum) pairs for launch_row_candidates.
+hipError_t launch_row_topk(const float* logits, int64_t ld, int B, int W, int C, int k, double thresh,
+                           int32_t* topk_idx, float* topk_logp, float* blank_logp, float* stats,
+                           int32_t* cand_count, hipStream_t s);
+hipError_t launch_row_candidates(const float* logits, int64_t ld, int B, int W, int C, double thresh,
+                                 const float* stats, const int64_t* cand_off, int32_t* cand_idx,
+                                 float* cand_logp, hipStream_t s);
+
+// contiguous rows [rows][C] -> float32 log-softmax per row
+hipError_t launch_log_softmax_rows(const float* x, int64_t rows, int C, float* y, hipStream_t s);
+
+}  // namespace hctr

@@ -1,0 +1,734 @@
+// gfx950 (MI355X / CDNA4) kernels for the hctr CNN+CTC inference path.
+//
+// Reference semantics (file:line relative to the reference root) are cited per kernel; the
+// tiling, layouts and fusion are this engine's own. Wavefront = 64 lanes throughout.
+#include "kernels.h"
+
+namespace hctr {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const void __attribute__((address_space(1))) * gptr_t;
+typedef void __attribute__((address_space(3))) * lptr_t;
+
+// -------------------------------------------------------------------------------------------
+// conv_mfma: 3x3 (pad 1) / 1x1 convolution + folded BatchNorm (+ReLU, +(2,1) max-pool,
+// +squeeze-excite partial sums) as an implicit GEMM on v_mfma_f32_16x16x32_f16.
+//
+// Reference ops fused here: nn.Conv2d(k,1,pad) -> BatchNorm2d(eval) -> ReLU -> max_pool2d((2,1))
+// (models/handwritten_ctr_model.py:116-150, 47-53) and the spatial sum that SELayer's
+// AdaptiveAvgPool2d needs (:27); in linear mode: self.linear (:175).
+//
+// GEMM view: D[cout][pixel] = sum_{tap,cin} Wt[tap][cout][cin] * X[pixel + tap][cin]
+//   MFMA A operand = weights (rows = couts), B operand = pixels (cols), so every lane ends up with
+//   16 consecutive couts of one pixel = one 32-byte NHWC store.
+// Block = WN x WM waves; each wave owns 64 couts x 64 pixels (4x4 MFMA tiles, 64 fp32 acc regs).
+//   conv mode: a wave's 64 pixels are a 4-row x 16-column patch; MFMA column c = image column,
+//   pixel repeat n = image row, so the (2,1) max-pool pairs repeats (0,1),(2,3) inside a lane.
+// K loop: taps x (Cin/64) steps; both operand tiles ([rows][64 cin] fp16 = 128-byte rows) are
+//   staged with global_load_lds_dwordx4 into a double-buffered LDS image. The zero padding of the
+//   convolution is stored in memory (1-pixel zero border), so a tap is only an address offset.
+// LDS image: linear per wave-instruction (8 rows x 128 B), 16-byte chunk index XOR (row & 7)
+//   applied on the global SOURCE address and again on the ds_read_b128 address (conflict-free for
+//   the 16x16x32 operand pattern; cdna guide rule 21).
+// -------------------------------------------------------------------------------------------
+template <int WN, int WM, int TAPS, bool LINEAR>
+__global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a) {
+    constexpr int NT = WN * WM * 64;
+    constexpr int BN = WN * 64, BM = WM * 64;
+    constexpr int NIW = BN * 8 / NT;     // 16-byte chunks of the weight tile per thread
+    constexpr int NIX = BM * 8 / NT;     // ... of the pixel tile
+    constexpr int TILE_BYTES = (BN + BM) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv / WM, wm = wv % WM;
+
+    // ---- block -> (m_tile, n_tile), XCD-aware: each XCD walks a contiguous run of the
+    //      (m-major, n-minor) order so the n-tiles of one pixel tile share that XCD's L2.
+    const int total = a.mtiles * a.ntiles;
+    int lin;
+    {
+        const int id = blockIdx.x, xcd = id & 7, s = id >> 3;
+        const int q = total >> 3, r = total & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + s;
+    }
+    const int nt = lin % a.ntiles;
+    const int mt = lin / a.ntiles;
+    const int n0 = nt * BN;
+
+    int img = 0, th = 0, tw = 0;
+    if (!LINEAR) {
+        tw = mt % a.tilesW;
+        const int t2 = mt / a.tilesW;
+        th = t2 % a.tilesH;
+        img = t2 / a.tilesH;
+    }
+    const int cin = a.Cin;
+
+    // ---- per-thread staging sources -------------------------------------------------------
+    const char* xsrc[NIX];
+    const char* wsrc[NIW];
+#pragma unroll
+    for (int i = 0; i < NIX; ++i) {
+        const int g = (wv * NIX + i) * 64 + lane;
+        const int row = g >> 3, cp = (g & 7) ^ (row & 7);
+        if (LINEAR) {
+            int64_t m = (int64_t)mt * BM + row;
+            if (m >= a.M) m = a.M - 1;
+            xsrc[i] = (const char*)(a.x + m * cin) + cp * 16;
+        } else {
+            const int h = th * (4 * WM) + (row >> 6) * 4 + ((row >> 4) & 3);
+            const int w = tw * kTileW + (row & 15);
+            xsrc[i] = (const char*)(a.x + img * a.in_sb + (int64_t)(h + 1) * a.in_sh +
+                                    (int64_t)(w + 1) * cin) + cp * 16;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+        const int g = (wv * NIW + i) * 64 + lane;
+        const int row = g >> 3, cp = (g & 7) ^ (row & 7);
+        wsrc[i] = (const char*)(a.w + (int64_t)(n0 + row) * cin) + cp * 16;
+    }
+
+    const int kc_steps = cin / kBK;
+    const int nk = TAPS * kc_steps;
+
+    auto stage = [&](int k, int buf) {
+        int tap = 0, kc = k;
+        if (TAPS > 1) { tap = k / kc_steps; kc = k - tap * kc_steps; }
+        int64_t xo = (int64_t)kc * (kBK * 2);
+        if (TAPS > 1) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            xo += ((int64_t)dy * a.in_sh + (int64_t)dx * cin) * 2;
+        }
+        const int64_t wo = ((int64_t)tap * a.CoutPad * cin + (int64_t)kc * kBK) * 2;
+        char* wdst = smem + buf * TILE_BYTES + (wv * NIW) * 1024;
+        char* xdst = smem + buf * TILE_BYTES + BN * 128 + (wv * NIX) * 1024;
+#pragma unroll
+        for (int i = 0; i < NIW; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + wo), (lptr_t)(wdst + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NIX; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + xo), (lptr_t)(xdst + i * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane fragment offsets inside a tile: row (lane&15), logical chunk ks*4 + (lane>>4)
+    const int q = lane >> 4;
+    const int frow = lane & 15;
+    const int foff0 = frow * 128 + (((0 + q) ^ (lane & 7)) << 4);
+    const int foff1 = frow * 128 + (((4 + q) ^ (lane & 7)) << 4);
+
+    stage(0, 0);
+    for (int k = 0; k < nk; ++k) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (k + 1 < nk) stage(k + 1, (k + 1) & 1);
+        const char* wt = smem + (k & 1) * TILE_BYTES + (wn * 64) * 128;
+        const char* xt = smem + (k & 1) * TILE_BYTES + BN * 128 + (wm * 64) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fo = ks ? foff1 : foff0;
+            f16x8 af[4], bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af[j] = *(const f16x8*)(wt + j * 2048 + fo);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bf[n] = *(const f16x8*)(xt + n * 2048 + fo);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], bf[n], acc[j][n], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------
+    // lane (q, c): couts n0 + wn*64 + q*16 + j*4 + i, pixel column c, pixel repeat n.
+    const int c = lane & 15;
+    const int co0 = n0 + wn * 64 + q * 16;
+    float bias[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 b4 = *(const f32x4*)(a.bias + co0 + j * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias[j * 4 + i] = b4[i];
+    }
+
+    if (LINEAR) {
+        float* out = (float*)a.y;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int64_t m = (int64_t)mt * BM + wm * 64 + n * 16 + c;
+            if (m < a.M) {
+                float* o = out + m * a.ldo + co0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = acc[j][n][i] + bias[j * 4 + i];
+                    *(f32x4*)(o + j * 4) = v;
+                }
+            }
+        }
+        return;
+    }
+
+    const int w = tw * kTileW + c;
+    const bool wvalid = w < a.W;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][n][i] += bias[j * 4 + i];
+
+    if (a.se_part != nullptr) {
+        // per-(image, channel) sums over this block's valid pixels, fixed reduction order
+        // (deterministic: lane tree -> LDS -> one partial row per block; reduced later by se_fc).
+        __syncthreads();                       // main-loop LDS no longer needed
+        float* red = (float*)smem;             // [WM][BN]
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float s = wvalid ? (acc[j][0][i] + acc[j][1][i]) + (acc[j][2][i] + acc[j][3][i]) : 0.f;
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                s += __shfl_xor(s, 4);
+                s += __shfl_xor(s, 8);
+                if (c == 0) red[wm * BN + wn * 64 + q * 16 + j * 4 + i] = s;
+            }
+        __syncthreads();
+        if (tid < BN) {
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) s += red[m * BN + tid];
+            const int64_t tile = (int64_t)img * (a.tilesH * a.tilesW) + th * a.tilesW + tw;
+            if (n0 + tid < a.Cout) a.se_part[tile * a.Cout + n0 + tid] = s;
+        }
+    }
+
+    half_t* out = (half_t*)a.y;
+    if (w < a.out_wlimit) {
+        const int hbase = th * (4 * WM) + wm * 4;
+        if (a.pool) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                f16x8 lo, hi;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = fmaxf(acc[e >> 2][2 * p][e & 3], acc[e >> 2][2 * p + 1][e & 3]);
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (!wvalid) v = 0.f;
+                    if (e < 8) lo[e] = (half_t)v; else hi[e - 8] = (half_t)v;
+                }
+                const int ho = (hbase >> 1) + p;
+                half_t* o = out + a.out_off + img * a.out_sb + (int64_t)ho * a.out_sh +
+                            (int64_t)w * a.out_sw + co0;
+                *(f16x8*)o = lo;
+                *(f16x8*)(o + 8) = hi;
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                f16x8 lo, hi;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[e >> 2][n][e & 3];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (!wvalid) v = 0.f;
+                    if (e < 8) lo[e] = (half_t)v; else hi[e - 8] = (half_t)v;
+                }
+                half_t* o = out + a.out_off + img * a.out_sb + (int64_t)(hbase + n) * a.out_sh +
+                            (int64_t)w * a.out_sw + co0;
+                *(f16x8*)o = lo;
+                *(f16x8*)(o + 8) = hi;
+            }
+        }
+    }
+}
+
+size_t conv_lds_bytes(ConvTile tile) {
+    return tile == TILE_64x256 ? 2 * (64 + 256) * 128 : 2 * (128 + 128) * 128;
+}
+
+template <int WN, int WM, int TAPS, bool LINEAR>
+static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
+    auto kern = conv_mfma_kernel<WN, WM, TAPS, LINEAR>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = a.mtiles * a.ntiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WN * WM * 64), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv(const ConvArgs& a, ConvTile tile, int taps, bool linear_f32, hipStream_t s) {
+    const size_t lds = conv_lds_bytes(tile);
+    if (linear_f32) return launch_conv_t<2, 2, 1, true>(a, lds, s);
+    if (tile == TILE_64x256) {
+        return taps == 9 ? launch_conv_t<1, 4, 9, false>(a, lds, s) : launch_conv_t<1, 4, 1, false>(a, lds, s);
+    }
+    return taps == 9 ? launch_conv_t<2, 2, 9, false>(a, lds, s) : launch_conv_t<2, 2, 1, false>(a, lds, s);
+}
+
+// -------------------------------------------------------------------------------------------
+// stem: NormalizePAD + conv0_1 (1 -> 64, 3x3, pad 1) + folded bn0_1 + ReLU, fp32 math, fp16 out.
+// utils/dataset.py:83-93 (x/255, (x-0.5)/0.5, replicate the last valid column to the batch width)
+// and models/handwritten_ctr_model.py:116-118. Memory-bound: 1 B in, 128 B out per pixel.
+// One thread = one pixel x 8 output channels (one 16-byte store).
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ img, int img_f32,
+                                                   const int32_t* __restrict__ widths,
+                                                   const float* __restrict__ w9,
+                                                   const float* __restrict__ bias,
+                                                   half_t* __restrict__ y, int B, int W, int Wa) {
+    __shared__ float sw[64 * 9];
+    __shared__ float sb[64];
+    for (int i = threadIdx.x; i < 64 * 9; i += 256) sw[i] = w9[i];
+    if (threadIdx.x < 64) sb[threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    const int cg = threadIdx.x & 7;                 // channel group of 8
+    const int64_t pix = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int64_t npix = (int64_t)B * 128 * W;
+    if (pix >= npix) return;
+    const int w = (int)(pix % W);
+    const int h = (int)((pix / W) % 128);
+    const int b = (int)(pix / ((int64_t)W * 128));
+    const int wlim = widths ? widths[b] : W;
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+        float x = 0.f;                                // conv zero padding (in normalised space)
+        if (hh >= 0 && hh < 128 && ww >= 0 && ww < W) {
+            const int wsrc = ww < wlim ? ww : wlim - 1;   // replicate pad
+            const int64_t off = ((int64_t)b * 128 + hh) * W + wsrc;
+            if (img_f32) {
+                x = ((const float*)img)[off];
+            } else {
+                x = (float)((const uint8_t*)img)[off] / 255.0f;
+                x = (x - 0.5f) / 0.5f;
+            }
+        }
+        v[t] = x;
+    }
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int co = cg * 8 + e;
+        float s = sb[co];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) s = fmaf(sw[co * 9 + t], v[t], s);
+        o[e] = (half_t)fmaxf(s, 0.f);
+    }
+    half_t* dst = y + (((int64_t)b * 130 + h + 1) * Wa + (w + 1)) * 64 + cg * 8;
+    *(f16x8*)dst = o;
+}
+
+hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, const float* w9,
+                       const float* bias, half_t* y, int B, int W, int Wa, hipStream_t s) {
+    const int64_t npix = (int64_t)B * 128 * W;
+    const int64_t grid = (npix + 31) / 32;
+    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)grid), dim3(256), 0, s, img, img_f32, widths_dev, w9,
+                       bias, y, B, W, Wa);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------
+// se_fc: SELayer's FC(c -> c/16) ReLU FC(c/16 -> c) sigmoid on the pooled means
+// (models/handwritten_ctr_model.py:19-29). One block per image; partial sums are reduced in a
+// fixed order so the result is bit-reproducible.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ part, int tiles,
+                                                    const float* __restrict__ w1,
+                                                    const float* __restrict__ w2,
+                                                    float* __restrict__ scale, int C, float inv_hw) {
+    __shared__ float mean[512];
+    __shared__ float hid[32];
+    const int b = blockIdx.x;
+    const int R = C / 16;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float* p = part + (int64_t)b * tiles * C + c;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int t = 0;
+        for (; t + 3 < tiles; t += 4) {
+            s0 += p[(int64_t)t * C];
+            s1 += p[(int64_t)(t + 1) * C];
+            s2 += p[(int64_t)(t + 2) * C];
+            s3 += p[(int64_t)(t + 3) * C];
+        }
+        for (; t < tiles; ++t) s0 += p[(int64_t)t * C];
+        mean[c] = ((s0 + s1) + (s2 + s3)) * inv_hw;
+    }
+    __syncthreads();
+    // hidden: R <= 32 outputs, 8 lanes each
+    {
+        const int r = threadIdx.x >> 3, l = threadIdx.x & 7;
+        float s = 0.f;
+        if (r < R)
+            for (int c = l; c < C; c += 8) s = fmaf(w1[r * C + c], mean[c], s);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (r < R && l == 0) hid[r] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s = fmaf(w2[c * R + r], hid[r], s);
+        scale[(int64_t)b * C + c] = 1.f / (1.f + expf(-s));
+    }
+}
+
+hipError_t launch_se_fc(const float* se_part, int tiles_per_img, const float* w1, const float* w2,
+                        float* scale, int B, int C, float inv_hw, hipStream_t s) {
+    hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), 0, s, se_part, tiles_per_img, w1, w2, scale, C, inv_hw);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------
+// se_apply: out = relu(o * scale[b][c] + residual), in place on o
+// (models/handwritten_ctr_model.py:30 and :57-58). Runs over the whole padded buffer: border
+// elements are 0 in both operands and stay 0. HBM-bound, 16-byte vectors.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se_apply_kernel(half_t* __restrict__ o, const half_t* __restrict__ r,
+                                                       const float* __restrict__ scale,
+                                                       int64_t img_vecs, int64_t total_vecs, int C) {
+    const int cv = C >> 3;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total_vecs; v += (int64_t)gridDim.x * 256) {
+        const int b = (int)(v / img_vecs);
+        const int c0 = (int)(v % cv) << 3;
+        const f16x8 ov = *(const f16x8*)(o + v * 8);
+        const f16x8 rv = *(const f16x8*)(r + v * 8);
+        const f32x4 s0 = *(const f32x4*)(scale + (int64_t)b * C + c0);
+        const f32x4 s1 = *(const f32x4*)(scale + (int64_t)b * C + c0 + 4);
+        f16x8 y;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sc = e < 4 ? s0[e] : s1[e - 4];
+            y[e] = (half_t)fmaxf(fmaf((float)ov[e], sc, (float)rv[e]), 0.f);
+        }
+        *(f16x8*)(o + v * 8) = y;
+    }
+}
+
+hipError_t launch_se_apply(half_t* o, const half_t* r, const float* scale, int64_t img_elems,
+                           int B, int C, hipStream_t s) {
+    const int64_t img_vecs = img_elems / 8, total = img_vecs * B;
+    int64_t grid = (total + 255) / 256;
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(se_apply_kernel, dim3((unsigned)grid), dim3(256), 0, s, o, r, scale, img_vecs, total, C);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------
+// argmax_rows: np.argmax(preds, 2) (utils/ctc_codec.py:75): first maximum wins.
+// One wave per row; lanes read 16-byte vectors; tie-break on the lower index.
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int64_t ld, int64_t M,
+                                                          int C, int32_t* __restrict__ idx, int tB, int tW) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* p = x + row * ld;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    const int c4 = C & ~3;
+    for (int c = lane * 4; c < c4; c += 256) {
+        const f32x4 v = *(const f32x4*)(p + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (v[e] > bv) { bv = v[e]; bi = c + e; }
+    }
+    for (int c = c4 + lane; c < C; c += 64) {
+        const float v = p[c];
+        if (v > bv) { bv = v; bi = c; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(bv, off);
+        const int oi = __shfl_xor(bi, off);
+        argmax_merge(bv, bi, ov, oi);
+    }
+    if (lane == 0) {
+        // tB > 0: input rows are r = t*tB + b (WBC order), output is [b][t]
+        const int64_t o = tB > 0 ? (row % tB) * tW + row / tB : row;
+        idx[o] = (bi == 0x7fffffff) ? 0 : bi;
+    }
+}
+
+hipError_t launch_argmax_rows(const float* logits, int64_t ld, int64_t M, int C, int32_t* idx, int tB, int tW,
+                              hipStream_t s) {
+    const int64_t grid = (M + 3) / 4;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)grid), dim3(256), 0, s, logits, ld, M, C, idx, tB, tW);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------
+// ctc_collapse: greedy CTC collapse (utils/ctc_codec.py:89-93): keep column t iff
+// idx[t] != 0 (blank) && idx[t] != C-1 (unknown) && !(t > 0 && idx[t-1] == idx[t]) - the
+// previous column is compared RAW. One wave per line; ballot + popcount compaction keeps order.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ctc_collapse_kernel(const int32_t* __restrict__ idx, int W, int C,
+                                                          int32_t* __restrict__ labels,
+                                                          int32_t* __restrict__ lengths) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int32_t* p = idx + (int64_t)b * W;
+    int32_t* o = labels + (int64_t)b * W;
+    int base = 0;
+    for (int t0 = 0; t0 < W; t0 += 64) {
+        const int t = t0 + lane;
+        int cur = 0, prev = -1;
+        if (t < W) {
+            cur = p[t];
+            if (t > 0) prev = p[t - 1];
+        }
+        const bool keep = (t < W) && cur != 0 && cur != C - 1 && cur != prev;
+        const unsigned long long m = __ballot(keep);
+        if (keep) o[base + __popcll(m & ((1ull << lane) - 1ull))] = cur;
+        base += __popcll(m);
+    }
+    if (lane == 0) lengths[b] = base;
+}
+
+hipError_t launch_ctc_collapse(const int32_t* idx, int B, int W, int C, int32_t* labels, int32_t* lengths,
+                               hipStream_t s) {
+    if (B == 0) return hipSuccess;
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(64), 0, s, idx, W, C, labels, lengths);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------
+// layout helpers for the API-parity paths (the fused fast path never materialises WBC logits)
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_to_wbc_kernel(const float* __restrict__ rows, int64_t ld, int B,
+                                                          int W, int C, float* __restrict__ out, int Bfull,
+                                                          int b0) {
+    const int64_t r = blockIdx.x;                  // sub-batch row index t*B + b
+    const int t = (int)(r / B), b = (int)(r % B);
+    const float* src = rows + ((int64_t)b * W + t) * ld;
+    float* dst = out + ((int64_t)t * Bfull + b0 + b) * C;
+    for (int c = threadIdx.x; c < C; c += 256) dst[c] = src[c];
+}
+
+__global__ __launch_bounds__(256) void wbc_to_rows_kernel(const float* __restrict__ wbc, int B, int W, int C,
+                                                          float* __restrict__ rows, int64_t ld) {
+    const int64_t r = blockIdx.x;                  // input row index t*B + b
+    const int t = (int)(r / B), b = (int)(r % B);
+    const float* src = wbc + r * C;
+    float* dst = rows + ((int64_t)b * W + t) * ld;
+    for (int c = threadIdx.x; c < C; c += 256) dst[c] = src[c];
+}
+
+hipError_t launch_logits_to_wbc(const float* logits, int64_t ld, int B, int W, int C, float* out, int Bfull,
+                                int b0, hipStream_t s) {
+    if ((int64_t)B * W == 0) return hipSuccess;
+    hipLaunchKernelGGL(rows_to_wbc_kernel, dim3((unsigned)((int64_t)B * W)), dim3(256), 0, s, logits, ld, B, W, C, out,
+                       Bfull, b0);
+    return hipGetLastError();
+}
+
+hipError_t launch_wbc_to_rows(const float* wbc, int B, int W, int C, float* rows, int64_t ld, hipStream_t s) {
+    if ((int64_t)B * W == 0) return hipSuccess;
+    hipLaunchKernelGGL(wbc_to_rows_kernel, dim3((unsigned)((int64_t)B * W)), dim3(256), 0, s, wbc, B, W, C, rows, ld);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------
+// row_topk: scipy.special.log_softmax (utils/ctc_codec.py:65) + the top-`search_depth`
+// candidates by descending log-prob (:127,186) + the count of candidates above ln(0.001) (:128,144).
+// One 256-thread block per (b, t) row; the row is held in LDS; k selection passes.
+// log-softmax is evaluated as the reference does in float32: tmp = x - max; tmp - log(sum(exp(tmp)));
+// the sum is accumulated in float64 (order-independent to fp32 precision).
+// Ties between equal log-probs: the lower class index comes first (the reference's order for
+// ties is numpy's unstable argsort, i.e. unspecified).
+// -------------------------------------------------------------------------------------------
+constexpr int kMaxRowLds = 12288;   // floats (48 KiB): supports C <= 12288
+
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__ x, int64_t ld, int B, int W,
+                                                       int C, int k, double thresh,
+                                                       int32_t* __restrict__ topk_idx,
+                                                       float* __restrict__ topk_logp,
+                                                       float* __restrict__ blank_logp,
+                                                       float* __restrict__ stats,
+                                                       int32_t* __restrict__ cand_count) {
+    __shared__ float row[kMaxRowLds];
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    __shared__ double rd[4];
+    const int64_t r = blockIdx.x;                  // t*B + b
+    const int t = (int)(r / B), b = (int)(r % B);
+    const float* p = x + ((int64_t)b * W + t) * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    float mx = -INFINITY;
+    for (int c = tid; c < C; c += 256) {
+        const float v = p[c];
+        row[c] = v;
+        mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) rv[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(rv[0], rv[1]), fmaxf(rv[2], rv[3]));
+    double s = 0.0;
+    for (int c = tid; c < C; c += 256) s += (double)expf(row[c] - mx);
+    s = block_sum_d(s, rd);
+    const float logs = logf((float)s);
+    // in-place: row[c] = log-prob (float32, as the reference computes it)
+    int cnt = 0;
+    for (int c = tid; c < C; c += 256) {
+        const float lp = (row[c] - mx) - logs;
+        row[c] = lp;
+        cnt += ((double)lp > thresh) ? 1 : 0;
+    }
+    if (cand_count) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+        __syncthreads();
+        if (lane == 0) ri[wv] = cnt;
+        __syncthreads();
+        if (tid == 0) cand_count[r] = ri[0] + ri[1] + ri[2] + ri[3];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        blank_logp[r] = row[0];
+        if (stats) { stats[2 * r] = mx; stats[2 * r + 1] = logs; }
+    }
+    float pv = INFINITY;
+    int pi = -1;
+    for (int j = 0; j < k; ++j) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = tid; c < C; c += 256) {
+            const float v = row[c];
+            const bool after = (v < pv) || (v == pv && c > pi);
+            if (after && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            argmax_merge(bv, bi, ov, oi);
+        }
+        __syncthreads();
+        if (lane == 0) { rv[wv] = bv; ri[wv] = bi; }
+        __syncthreads();
+        bv = rv[0]; bi = ri[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) argmax_merge(bv, bi, rv[q], ri[q]);
+        pv = bv; pi = bi;
+        if (tid == 0) {
+            topk_idx[r * k + j] = (bi == 0x7fffffff) ? 0 : bi;
+            topk_logp[r * k + j] = bv;
+        }
+    }
+}
+
+hipError_t launch_row_topk(const float* logits, int64_t ld, int B, int W, int C, int k, double thresh,
+                           int32_t* topk_idx, float* topk_logp, float* blank_logp, float* stats,
+                           int32_t* cand_count, hipStream_t s) {
+    if ((int64_t)B * W == 0) return hipSuccess;
+    if (C > kMaxRowLds) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(row_topk_kernel, dim3((unsigned)((int64_t)B * W)), dim3(256), 0, s, logits, ld, B, W, C, k,
+                       thresh, topk_idx, topk_logp, blank_logp, stats, cand_count);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void row_candidates_kernel(const float* __restrict__ x, int64_t ld, int B, int W,
+                                                            int C, double thresh, const float* __restrict__ stats,
+                                                            const int64_t* __restrict__ cand_off,
+                                                            int32_t* __restrict__ cand_idx,
+                                                            float* __restrict__ cand_logp) {
+    // ascending class order, like np.where (utils/ctc_codec.py:144). stats[2r], stats[2r+1] are the
+    // row max and log-sum from row_topk, so the float32 log-prob is recomputed bit-identically.
+    const int64_t r = blockIdx.x;
+    const int t = (int)(r / B), b = (int)(r % B);
+    const float* p = x + ((int64_t)b * W + t) * ld;
+    const float mx = stats[2 * r], logs = stats[2 * r + 1];
+    const int lane = threadIdx.x;
+    int64_t base = cand_off[r];
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
+        float lp = 0.f;
+        bool keep = false;
+        if (c < C) {
+            lp = (p[c] - mx) - logs;
+            keep = (double)lp > thresh;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const int64_t o = base + __popcll(m & ((1ull << lane) - 1ull));
+            cand_idx[o] = c;
+            cand_logp[o] = lp;
+        }
+        base += __popcll(m);
+    }
+}
+
+// log_softmax_rows: scipy.special.log_softmax(preds, axis=2) (utils/ctc_codec.py:65) for the whole
+// tensor, float32 in / float32 out, same arithmetic as row_topk. Rows are independent (any layout).
+__global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x, int C,
+                                                               float* __restrict__ y) {
+    __shared__ float rv[4];
+    __shared__ double rd[4];
+    const int64_t r = blockIdx.x;
+    const float* p = x + r * C;
+    float* o = y + r * C;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float mx = -INFINITY;
+    for (int c = tid; c < C; c += 256) mx = fmaxf(mx, p[c]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) rv[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(rv[0], rv[1]), fmaxf(rv[2], rv[3]));
+    double s = 0.0;
+    for (int c = tid; c < C; c += 256) s += (double)expf(p[c] - mx);
+    s = block_sum_d(s, rd);
+    const float logs = logf((float)s);
+    for (int c = tid; c < C; c += 256) o[c] = (p[c] - mx) - logs;
+}
+
+hipError_t launch_log_softmax_rows(const float* x, int64_t rows, int C, float* y, hipStream_t s) {
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, x, C, y);
+    return hipGetLastError();
+}
+
+hipError_t launch_row_candidates(const float* logits, int64_t ld, int B, int W, int C, double thresh,
+                                 const float* stats, const int64_t* cand_off, int32_t* cand_idx,
+                                 float* cand_logp, hipStream_t s) {
+    if ((int64_t)B * W == 0) return hipSuccess;
+    hipLaunchKernelGGL(row_candidates_kernel, dim3((unsigned)((int64_t)B * W)), dim3(64), 0, s, logits, ld, B, W, C,
+                       thresh, stats, cand_off, cand_idx, cand_logp);
+    return hipGetLastError();
+}
+
+}  // namespace hctr

@@ -1,0 +1,164 @@
+/*
+ * hctr_hip.h - C ABI of libhctr_hip.so, the MI355X (gfx950) engine for the reference's
+ * hctr CNN+CTC inference path.
+ *
+ * The reference (AndrewCullacino/handwritten-chinese-ocr-samples) has no FFI layer: the seam
+ * for this path is two Python classes plus a checkpoint dict. Each entry point
+ * below names the reference interface it stands behind (file:line relative to the reference
+ * root). The Python shims in handwritten-chinese-ocr-samples_amd/{model,codec}.py bind these
+ * with ctypes and keep the reference's class/method signatures; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every host buffer for the duration of a call;
+ *     the library owns device memory, workspace and the context;
+ *   - every function returns 0 (HCTR_OK) or a negative hctr_status; the message for the last
+ *     failure on a context is hctr_last_error(ctx); no C++ exception crosses the ABI;
+ *   - a context is bound to one device and one HIP stream and is NOT re-entrant; use one context
+ *     per thread/GPU. Calls are synchronous at return unless documented otherwise;
+ *   - "WBC" = [W][B][C] row-major float32, the layout hctr_model.forward returns
+ *     (models/handwritten_ctr_model.py:171-178).
+ */
+#ifndef HCTR_HIP_H
+#define HCTR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hctr_ctx hctr_ctx;
+
+typedef enum {
+    HCTR_OK = 0,
+    HCTR_ERR_ARG = -1,        /* bad argument (-> ValueError) */
+    HCTR_ERR_HIP = -2,        /* HIP runtime failure, message has file:line (-> RuntimeError) */
+    HCTR_ERR_STATE = -3,      /* call order violated, e.g. forward before finalize (-> RuntimeError) */
+    HCTR_ERR_KEY = -4,        /* unknown / missing state-dict key (-> KeyError, as load_state_dict strict) */
+    HCTR_ERR_SHAPE = -5,      /* tensor shape mismatch (-> RuntimeError, as load_state_dict) */
+    HCTR_ERR_EMPTY_LINE = -6, /* beam search on a line whose greedy decode is empty, or whose beam set
+                                 became empty: the reference raises IndexError (utils/ctc_codec.py:143,198,179) */
+    HCTR_ERR_NOMEM = -7
+} hctr_status;
+
+typedef enum { HCTR_U8 = 0, HCTR_F32 = 1, HCTR_I64 = 2 } hctr_dtype;
+
+/* ---- context: replaces hctr_model(num_classes) + .cuda(gpu) ---------------------------------
+ * models/handwritten_ctr_model.py:156-169, test.py:143-148. num_classes = 1 + len(chars) + 1. */
+int hctr_create(hctr_ctx** out, int device, int num_classes);
+void hctr_destroy(hctr_ctx* ctx);
+const char* hctr_last_error(const hctr_ctx* ctx);   /* ctx may be NULL: last create() failure */
+const char* hctr_version(void);
+
+/* ---- weight ingest: replaces model.load_state_dict(checkpoint['state_dict']) -----------------
+ * test.py:152-153; key schema main.py:349-356 / SURVEY.md 8b (254 entries). Call once per entry
+ * (any order), then hctr_finalize_weights, which checks completeness, folds eval-mode BatchNorm
+ * (eps 1e-5) into the preceding conv, converts to the kernel layouts and uploads. fp32 tensors are
+ * HCTR_F32; num_batches_tracked entries are HCTR_I64 and ignored. */
+int hctr_load_tensor(hctr_ctx* ctx, const char* key, const void* host_ptr,
+                     const int64_t* shape, int ndim, int dtype);
+int hctr_finalize_weights(hctr_ctx* ctx);
+
+/* ---- forward: replaces hctr_model.forward --------------------------------------------------
+ * models/handwritten_ctr_model.py:171-178 (trunk :115-153). Input: a batch of B line images of
+ * height 128 and common width W, either HCTR_F32 [B][1][128][W] already normalised to [-1,1]
+ * (what test.py:179-193 feeds), or HCTR_U8 [B][128][W] raw grey levels, in which case the engine
+ * applies NormalizePAD itself (utils/dataset.py:83-93): x/255, (x-0.5)/0.5, and columns
+ * >= widths[b] replicate column widths[b]-1 (widths may be NULL = all W).
+ * img_on_device / out_on_device: the pointer is a device pointer on ctx's device.
+ * Output: float32 logits in WBC layout, B*W*num_classes values. */
+int hctr_forward_logits(hctr_ctx* ctx, const void* img, int img_dtype, int img_on_device,
+                        const int32_t* widths, int B, int W,
+                        float* out_wbc, int out_on_device);
+
+/* ---- fused forward + greedy decode: replaces model(x) -> codec.decode(...) greedy ------------
+ * test.py:191-194 with utils/ctc_codec.py:70-99. Logits never leave the device; argmax takes the
+ * first maximum (np.argmax), a column is kept iff idx!=0 && idx!=C-1 && idx!=previous raw idx.
+ * labels: int32 [B][W] (first lengths[b] entries valid), lengths: int32 [B]; host pointers. */
+int hctr_greedy(hctr_ctx* ctx, const void* img, int img_dtype, int img_on_device,
+                const int32_t* widths, int B, int W,
+                int32_t* labels, int32_t* lengths);
+
+/* ---- decode of caller-supplied logits: replaces ctc_codec.decode(ndarray) greedy -------------
+ * utils/ctc_codec.py:63-99. logits: float32 WBC with C classes (host or device pointer). */
+int hctr_decode_greedy_logits(hctr_ctx* ctx, const float* logits_wbc, int on_device,
+                              int W, int B, int C, int32_t* labels, int32_t* lengths);
+
+/* ---- beam-search front end on the device -----------------------------------------------------
+ * utils/ctc_codec.py:65 (log_softmax), :127/:186 (top search_depth by descending log-prob), :128,144
+ * (candidates with log-prob > ln 0.001 for the "skip" variant).
+ * Runs the forward on img (or, when img == NULL, takes caller logits in WBC layout), then
+ * log-softmax and top-k per (t, b), and copies to the host buffers
+ *   topk_idx  int32 [W][B][k], topk_logp float32 [W][B][k]   (descending; ties: lower index first)
+ *   blank_logp float32 [W][B]                                 (log-prob of class 0).
+ * With want_candidates != 0 it also builds, per (t, b), the ascending list of classes whose
+ * log-prob exceeds ln(0.001); the context keeps those lists until hctr_beam_fetch_candidates copies
+ * them out: cand_off int64 [W*B+1] (CSR, row r = t*B + b), cand_idx int32 / cand_logp float32 of
+ * *num_candidates entries. */
+int hctr_beam_frontend(hctr_ctx* ctx, const void* img, int img_dtype, int img_on_device,
+                       const int32_t* widths, const float* logits_wbc, int logits_on_device,
+                       int B, int W, int C, int k, int want_candidates,
+                       int32_t* topk_idx, float* topk_logp, float* blank_logp,
+                       int64_t* num_candidates);
+int hctr_beam_fetch_candidates(hctr_ctx* ctx, int64_t* cand_off, int32_t* cand_idx, float* cand_logp);
+
+/* ---- log-softmax of caller logits: replaces scipy.special.log_softmax(preds, axis=2) ------------
+ * utils/ctc_codec.py:65. float32 WBC in (host or device), float32 WBC out (host). Only needed when
+ * the language model proposes candidates (use_tfm_pred), because those can be any class. */
+int hctr_log_softmax(hctr_ctx* ctx, const float* logits_wbc, int on_device, int W, int B, int C,
+                     float* out_host);
+
+/* ---- host prefix beam search: replaces ctc_codec.__cbs_full__/__cbs_skip__ -------------------
+ * utils/ctc_codec.py:124-285 (Beam :288-307), float64 accumulators over float32 log-probs.
+ * The language model stays behind callbacks, as in the reference (kenlm / transformer objects are
+ * duck-typed there, utils/ctc_codec.py:216-219,269-281):
+ *   score_cb: called once per time step with n sentences (label ids of prefix+suffix, CSR in
+ *             ids/offs); must fill scores[n]. Replaces ngram.score(' '.join(chars), eos=False)
+ *             / transformer.score(batch, char_based=True).
+ *   next_cb:  optional (use_tfm_pred): for n beam prefixes fill out_ids[n][k] with the LM's k most
+ *             likely next labels (utils/ctc_codec.py:216-227); NULL disables.
+ * builtin_lm: 0 = callbacks, 1 = zero LM, 2 = toy hashed bigram over code points (needs
+ *             label_codepoints[C]); built-ins make the multi-threaded path callback-free.
+ * full_logp_wbc: float32 [W][B][C] log-probs, required only with next_cb (LM-proposed labels can be
+ *             any class); NULL otherwise. cand_* are required only when skip_search != 0.
+ * Per-line results: out_labels int32 [B][W] + out_lengths [B]. line_status[b] is HCTR_OK or
+ * HCTR_ERR_EMPTY_LINE; the return value is the first non-OK line status. */
+typedef int (*hctr_lm_score_cb)(void* user, int n, const int32_t* ids, const int32_t* offs, double* scores);
+typedef int (*hctr_lm_next_cb)(void* user, int n, const int32_t* ids, const int32_t* offs, int k, int32_t* out_ids);
+
+typedef struct {
+    int skip_search;        /* utils/ctc_codec.py:40,66 */
+    int beam_size;          /* :37 */
+    int search_depth;       /* :36 */
+    double lm_panelty;      /* :34 (spelling is the reference's) */
+    double len_bonus;       /* :35 */
+    int builtin_lm;
+    const int32_t* label_codepoints;  /* [C] unicode code point per label, for builtin_lm == 2 */
+    hctr_lm_score_cb score_cb;
+    hctr_lm_next_cb next_cb;
+    void* user;
+    int num_threads;        /* lines in parallel; forced to 1 when callbacks are used */
+} hctr_beam_params;
+
+int hctr_beam_search(const hctr_beam_params* p, int W, int B, int C, int k,
+                     const int32_t* topk_idx, const float* topk_logp, const float* blank_logp,
+                     const int64_t* cand_off, const int32_t* cand_idx, const float* cand_logp,
+                     const float* full_logp_wbc,
+                     int32_t* out_labels, int32_t* out_lengths, int32_t* line_status);
+
+/* ---- introspection used by bench.py / tests ---------------------------------------------------
+ * Per-layer device time of the last forward (HIP events on the context's stream), in call order.
+ * names: '\n'-separated layer names written into buf (cap bytes); ms: float array of n entries.
+ * Returns the number of layers recorded (or a negative status). Enabled by hctr_set_profiling. */
+int hctr_set_profiling(hctr_ctx* ctx, int enabled);
+int hctr_last_profile(hctr_ctx* ctx, char* names_buf, int cap, float* ms, int max_n);
+/* Debug taps for bisecting parity: copy an intermediate activation of the last forward to the host
+ * as float32 NCHW [B][C][H][W]. name: "stage0".."stage4", "conv0_1". Returns element count or <0. */
+int64_t hctr_debug_activation(hctr_ctx* ctx, const char* name, float* out, int64_t cap,
+                              int* C, int* H);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HCTR_HIP_H */

@@ -1,0 +1,198 @@
+"""GPU parity tests (-m gpu): the HIP engine, called through the C ABI, against the oracle and the
+committed golden fixtures (outputs of the real reference).
+
+Tolerances (fp16 storage / fp16 MFMA inputs / fp32 accumulate vs the fp32 CPU reference; the
+reference's own GPU mode is TF32, the same 10-bit mantissa):
+  logits      |err| <= LOGIT_RTOL * max|logit| + LOGIT_ATOL
+  argmax      bit-exact on every column whose reference top-2 margin exceeds 4x the measured error
+  decoded text exact when every column of the line is such a "safe" column (otherwise the line is
+              compared through its safe columns only and the count of ambiguous columns is bounded)
+Integer / index work (collapse, top-k order, candidate lists, beam search) is bit-exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import codec_cases
+from conftest import GOLDEN
+from oracle import ctc_ref, hctr_ref
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_RTOL = 0.01
+LOGIT_ATOL = 0.05
+
+
+@pytest.fixture(scope="module")
+def engine(pkg, synth, state_dict):
+    m = pkg.hctr_model(synth.DEFAULT_VOCAB + 2).cuda(0)
+    m.load_state_dict(state_dict)
+    m.eval()
+    return m
+
+
+@pytest.fixture(scope="module")
+def codec(pkg, synth, engine):
+    return pkg.ctc_codec(synth.characters()).attach(engine)
+
+
+def _safe(ref, err):
+    srt = np.sort(ref, axis=2)
+    return (srt[:, :, -1] - srt[:, :, -2]) > 4 * err
+
+
+@pytest.mark.parametrize("name,seed,widths", [("b1w32", 21, [32]), ("b3w67u", 22, [67, 50, 33]),
+                                              ("b2w96", 23, [96, 96])])
+def test_forward_matches_reference_fixture(engine, synth, name, seed, widths):
+    """Engine logits vs the REAL reference's logits (tests/golden/model_small.npz)."""
+    g = np.load(os.path.join(GOLDEN, "model_small.npz"))
+    imgs = synth.make_line_images(len(widths), max(widths), seed)
+    got = engine(imgs, widths=widths)
+    sub = g["sub_classes"]
+    ref_sub = g[name + "/logits_sub"]
+    tol = LOGIT_RTOL * float(np.abs(ref_sub).max()) + LOGIT_ATOL
+    err = float(np.abs(got[:, :, sub] - ref_sub).max())
+    assert err <= tol, "max logit error %.4f > %.4f" % (err, tol)
+    margin = g[name + "/top10_val"][:, :, 0] - g[name + "/top10_val"][:, :, 1]
+    safe = margin > 4 * err
+    assert safe.mean() > 0.9
+    assert np.array_equal(got.argmax(axis=2)[safe], g[name + "/argmax"][safe].astype(np.int64))
+    # activations along the trunk (debug taps) against the reference's
+    for tap in ("stage0", "stage2", "stage4"):
+        a = engine.debug_activation(tap, len(widths))[:, :8, :, :16]
+        r = g[name + "/act/" + tap]
+        assert np.abs(a - r).max() <= 0.02 * np.abs(r).max() + 0.02, tap
+
+
+def test_input_paths_agree(engine, synth):
+    """uint8 + widths (device NormalizePAD) == float32 pre-normalised input (utils/dataset.py:83-93)."""
+    widths = [80, 41, 80, 7]
+    imgs = synth.make_line_images(4, 80, 77)
+    a = engine(imgs, widths=widths)
+    b = engine(synth.normalize_pad(imgs, widths))
+    assert np.array_equal(a, b)
+    import torch
+    c = engine(torch.from_numpy(synth.normalize_pad(imgs, widths)).cuda())
+    assert c.is_cuda and np.array_equal(c.cpu().numpy(), a)
+
+
+def test_fused_greedy_equals_decode_of_logits(engine, codec, synth):
+    """hctr_greedy (fused) == argmax+collapse of the engine's own logits == oracle codec on them:
+    integer work, bit-exact."""
+    imgs = synth.make_line_images(3, 200, 5)
+    logits = engine(imgs)
+    fused = codec.labels_to_text(engine.greedy(imgs))
+    assert fused == codec.decode(logits)
+    assert fused == ctc_ref.CtcCodecRef(synth.characters()).decode(logits)
+
+
+@pytest.mark.parametrize("name,seed,w", [("w488", 31, 488), ("w2000", 32, 2000)])
+def test_long_line_against_reference_fixture(engine, codec, synth, name, seed, w):
+    """Config-2 width (2000) and a bundled-image width (488): argmax on safe columns and decoded text
+    vs the real reference (tests/golden/model_lines.npz, model_strings.json)."""
+    g = np.load(os.path.join(GOLDEN, "model_lines.npz"))
+    with open(os.path.join(GOLDEN, "model_strings.json")) as f:
+        strings = json.load(f)
+    imgs = synth.make_line_images(1, w, seed)
+    got = engine(imgs)
+    err = float(np.abs(got.max(axis=2) - g[name + "/max"]).max())
+    tol = LOGIT_RTOL * float(np.abs(g[name + "/max"]).max()) + LOGIT_ATOL
+    assert err <= tol
+    margin = g[name + "/top10_val"][:, :, 0] - g[name + "/top10_val"][:, :, 1]
+    safe = margin > 4 * max(err, 1e-3)
+    amax = got.argmax(axis=2)
+    assert np.array_equal(amax[safe], g[name + "/argmax"][safe].astype(np.int64))
+    ambiguous = int((~safe).sum())
+    assert ambiguous <= 0.03 * w
+    text = codec.labels_to_text(engine.greedy(imgs))[0]
+    ref_text = strings[name]["greedy"][0]
+    dist = ctc_ref.edit_distance(text, ref_text)
+    assert dist <= 2 * ambiguous, (dist, ambiguous)
+    if ambiguous == 0:
+        assert text == ref_text
+
+
+def test_config1_bundled_images(engine, codec):
+    """BASELINE config 1: the five bundled sample lines (W = 3514, 908, 2375, 1913, 488)."""
+    g = np.load(os.path.join(GOLDEN, "images_c1.npz"))
+    with open(os.path.join(GOLDEN, "model_strings.json")) as f:
+        strings = json.load(f)
+    for key in sorted({k.split("/")[0] for k in g.files}):
+        img = g[key + "/image"]
+        got = engine(img[None])
+        err = float(np.abs(got.max(axis=2) - g[key + "/max"]).max())
+        assert err <= LOGIT_RTOL * float(np.abs(g[key + "/max"]).max()) + LOGIT_ATOL, key
+        safe = g[key + "/top2_margin"] > 4 * max(err, 1e-3)
+        assert np.array_equal(got.argmax(axis=2)[safe], g[key + "/argmax"][safe].astype(np.int64)), key
+        text = codec.labels_to_text(engine.greedy(img[None]))[0]
+        dist = ctc_ref.edit_distance(text, strings["c1_" + key]["greedy"][0])
+        assert dist <= 2 * int((~safe).sum()), key
+
+
+def test_codec_cases_on_device(pkg):
+    """ctc_codec.decode on caller logits: greedy + both beam variants, vs the REAL reference codec's
+    outputs (tests/golden/codec_cases.json). Bit-exact (strings)."""
+    with open(os.path.join(GOLDEN, "codec_cases.json")) as f:
+        gold = json.load(f)
+    for name, seed, w, b, c, style in codec_cases.CODEC_CASES:
+        logits = codec_cases.gen_logits(seed, w, b, c, style)
+        chars = codec_cases.vocab(c)
+        cd = pkg.ctc_codec(chars)
+        assert cd.decode(logits) == gold[name]["greedy"], name
+        for tag, skip, lm, lp, lb, bs, depth in codec_cases.BEAM_SETTINGS:
+            cd = pkg.ctc_codec(chars)
+            cd.use_beam_search, cd.skip_search, cd.use_tfm_pred = True, skip, False
+            cd.lm_panelty, cd.len_bonus, cd.beam_size, cd.search_depth = lp, lb, bs, depth
+            cd.ngram = pkg.ZeroLM() if lm == "zero" else pkg.ToyBigramLM()
+            try:
+                got = cd.decode(logits)
+            except IndexError:
+                got = "IndexError"
+            assert got == gold[name][tag], (name, tag)
+        # the callback path (a user LM object) must give the same strings as the built-in LM
+        cd = pkg.ctc_codec(chars)
+        cd.use_beam_search, cd.use_tfm_pred = True, False
+        cd.lm_panelty, cd.len_bonus = 0.8, 4.8
+        cd.ngram = ctc_ref.ToyBigramLM()
+        assert cd.decode(logits) == gold[name]["full_toy"], name
+
+
+def test_beam_on_model_logits(engine, pkg, synth):
+    """Beam search end to end (fused front end) vs the oracle codec run on the engine's own logits
+    (isolates decode parity from fp16 logit differences), and vs the reference fixture strings."""
+    imgs = synth.make_line_images(2, 160, 41)
+    logits = engine(imgs)
+    for tag, skip, lm, lp, lb, bs, depth in codec_cases.BEAM_SETTINGS[:4]:
+        cd = pkg.ctc_codec(synth.characters()).attach(engine)
+        cd.use_beam_search, cd.skip_search, cd.use_tfm_pred = True, skip, False
+        cd.lm_panelty, cd.len_bonus, cd.beam_size, cd.search_depth = lp, lb, bs, depth
+        cd.ngram = pkg.ZeroLM() if lm == "zero" else pkg.ToyBigramLM()
+        fe = engine.beam_frontend(imgs, k=depth, want_candidates=skip)
+        fused = cd.decode_frontend(fe)
+        assert fused == cd.decode(logits), tag
+        oc = ctc_ref.CtcCodecRef(synth.characters())
+        oc.use_beam_search, oc.skip_search, oc.use_tfm_pred = True, skip, False
+        oc.lm_panelty, oc.len_bonus, oc.beam_size, oc.search_depth = lp, lb, bs, depth
+        oc.ngram = ctc_ref.ZeroLM() if lm == "zero" else ctc_ref.ToyBigramLM()
+        assert fused == oc.decode(logits), tag
+
+
+def test_error_behaviour(pkg, synth, state_dict):
+    m = pkg.hctr_model(synth.DEFAULT_VOCAB + 2)
+    with pytest.raises(RuntimeError):
+        m(np.zeros((1, 1, 128, 32), np.float32))          # never moved to a GPU: no CPU fallback
+    m.cuda(0)
+    bad = dict(state_dict)
+    bad.pop("cnn.block2.1.se.fc.0.weight")
+    with pytest.raises(KeyError):
+        m.load_state_dict(bad)
+    m2 = pkg.hctr_model(synth.DEFAULT_VOCAB + 2).cuda(0)
+    bad = dict(state_dict)
+    bad["extra.weight"] = np.zeros((1,), np.float32)
+    with pytest.raises(KeyError):
+        m2.load_state_dict(bad)
+    m3 = pkg.hctr_model(100).cuda(0)
+    with pytest.raises(RuntimeError):
+        m3.load_state_dict(state_dict)                     # linear.weight shape mismatch
