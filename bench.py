@@ -1,0 +1,155 @@
+"""bench.py - hot-path throughput of the hctr engine on MI355X (driver contract: see DESIGN.md).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (NormalizePAD -> hctr trunk -> head -> argmax -> CTC collapse ->
+labels on the host, + one RCCL gather to rank 0 when N > 1) over one batch of synthetic line images
+per GPU: BASELINE.json configs[1], B=64 lines of 1x128x2000 per GPU, greedy decode. Inputs are
+uint8 images already resident in HBM when the timed region starts. Weak scaling: per-GPU work is
+fixed, value = all ranks' lines / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel, HIP events on the engine's own
+stream during the timed steps) and `cpu_baseline` (the oracle restatement on the host cores, bounded
+sample) objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W_LINE = 2000
+B_PER_GPU = 64
+SEED = 2
+FLOP_PER_COL_DOM = 75.497472e6        # one 3x3 512->512 @ H=16 layer, per pixel column
+FLOP_PER_COL_ALL = 1358.838912e6      # whole forward per pixel column at C=7358
+PEAK_F16_TFLOPS = 2500.0              # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+DOMINANT = ("block3.1.conv1", "block3.1.conv2", "block3.2.conv1", "block3.2.conv2", "block3.3.conv1",
+            "block3.3.conv2", "block3.4.conv1", "block3.4.conv2", "block3.0.conv2", "conv3+pool")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="lines per GPU")
+    ap.add_argument("--width", type=int, default=W_LINE)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-lines", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import hctr_amd
+    synth = hctr_amd.synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+
+    C = synth.DEFAULT_VOCAB + 2
+    B, W = args.batch, args.width
+    sd = synth.make_state_dict(C, seed=0)
+    model = hctr_amd.hctr_model(C).cuda(local)
+    model.load_state_dict(sd)
+    model.eval()
+    # this rank's contiguous shard of the global synthetic batch (seed, global line index)
+    imgs_host = synth.make_line_images(B, W, SEED, line_offset=rank * B)
+    imgs = torch.from_numpy(imgs_host).to(dev)              # resident in HBM before timing
+    torch.cuda.synchronize(dev)
+    n_global = B * world
+
+    def step():
+        labels = model.greedy(imgs)
+        if dist is not None:
+            return hctr_amd.package.dist.gather_labels(labels, n_global, W, device=dev)
+        return labels
+
+    for _ in range(args.warmup):
+        out = step()
+    model.set_profiling(True)
+    prof = {}
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        for name, ms in model.last_profile():
+            prof.setdefault(name, []).append(ms)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    model.set_profiling(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    lines_per_s = n_global * args.steps / dt
+    cols = B * W
+    dom_ms = [np.mean(prof[n]) for n in DOMINANT if n in prof]
+    dom_avg_ms = float(np.mean(dom_ms)) if dom_ms else float("nan")
+    dom_tflops = FLOP_PER_COL_DOM * cols / (dom_avg_ms * 1e-3) / 1e12
+    kernel_ms = float(sum(np.mean(v) for v in prof.values()))
+    result = {
+        "metric": "text-lines/sec (1x128x2000 synth) greedy decode",
+        "value": round(lines_per_s, 3), "unit": "lines/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16 (f32 accumulate)", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: B=%d x 1x128x%d uint8 lines per GPU, random-init hctr "
+                               "(C=%d), forward + greedy CTC decode, labels to host" % (B, W, C),
+                   "lines_per_gpu": B, "width": W, "classes": C, "parallelism": "batch-shard x%d" % world},
+        "roofline": {"bound": "mfma", "kernel": "conv_mfma 3x3 512->512 @H=16 (10 launches/step)",
+                     "achieved": round(dom_tflops, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(dom_tflops / PEAK_F16_TFLOPS, 4), "traffic": None,
+                     "avg_launch_ms": round(dom_avg_ms, 4),
+                     "flops_per_launch": FLOP_PER_COL_DOM * cols},
+        "whole_forward": {"kernel_ms_per_step": round(kernel_ms, 3),
+                          "tflops": round(FLOP_PER_COL_ALL * cols / (kernel_ms * 1e-3) / 1e12, 2)},
+    }
+
+    if not args.no_cpu_baseline:
+        from oracle import ctc_ref, hctr_ref
+        nl = max(1, args.cpu_lines)
+        x = synth.normalize_pad(imgs_host[:nl])
+        codec = ctc_ref.CtcCodecRef(synth.characters())
+        hctr_ref.forward(sd, x[:1, :, :, :64])                       # warm-up
+        t0 = time.perf_counter()
+        ref = hctr_ref.forward(sd, x).numpy()
+        ref_txt = codec.decode(ref)
+        cdt = time.perf_counter() - t0
+        got_txt = [codec.characters and "".join(codec.characters[i] for i in lab) for lab in out[:nl]]
+        ed = sum(ctc_ref.edit_distance(a, b) for a, b in zip(got_txt, ref_txt))
+        result["cpu_baseline"] = {"value": round(nl / cdt, 4), "unit": "lines/s", "cores": torch.get_num_threads(),
+                                  "kind": "port", "sample": "%d line(s) of 1x128x%d, oracle forward + greedy "
+                                  "(torch CPU fp32)" % (nl, W)}
+        result["parity_vs_cpu"] = {"lines": nl, "exact_lines": int(sum(a == b for a, b in zip(got_txt, ref_txt))),
+                                   "char_edits": int(ed), "ref_chars": int(sum(len(s) for s in ref_txt))}
+    print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,62 @@
+"""Multi-GPU batch sharding for the hctr path: one process per GPU, contiguous line ranges per rank,
+no activation exchange, and ONE gather of the decoded label sequences to rank 0.
+
+The reference has no multi-device inference (test.py:143-148 is single device; NCCL appears only in
+training DDP, main.py:226-237). ``torch.distributed`` is plumbing here: backend "nccl" is RCCL over
+xGMI on the GPU box, "gloo" on CPU for tests. The message is tiny (<= 4 MB per rank), so a direct
+gather is latency-bound and the xGMI link rate is irrelevant.
+"""
+import numpy as np
+
+
+def shard_range(n_lines, rank, world):
+    """Contiguous range [lo, hi) of lines owned by ``rank`` (sizes differ by at most one)."""
+    base, rem = divmod(n_lines, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_labels(label_lists, cap):
+    """[n][1 + cap] int32: column 0 = length, then the labels (zero padded)."""
+    out = np.zeros((len(label_lists), 1 + cap), dtype=np.int32)
+    for i, lab in enumerate(label_lists):
+        n = len(lab)
+        if n > cap:
+            raise ValueError("label sequence longer than cap")
+        out[i, 0] = n
+        out[i, 1:1 + n] = lab
+    return out
+
+
+def unpack_labels(packed):
+    return [row[1:1 + row[0]].copy() for row in packed]
+
+
+def gather_labels(label_lists, n_lines, cap, device=None, group=None):
+    """Gather every rank's decoded lines to rank 0 in global line order with ONE collective.
+
+    Each rank passes the label arrays of its ``shard_range`` lines. All ranks send a buffer padded
+    to the largest shard (ceil(n_lines / world)) so the collective is a plain ``gather``.
+    Returns the full list on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    per = -(-n_lines // world)
+    buf = np.zeros((per, 1 + cap), dtype=np.int32)
+    mine = pack_labels(label_lists, cap)
+    buf[:mine.shape[0]] = mine
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    if dist.get_backend(group) == "nccl" or rank == 0:
+        outs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+    else:
+        outs = None
+    dist.gather(t, outs, dst=0, group=group)
+    if rank != 0:
+        return None
+    result = []
+    for r in range(world):
+        lo, hi = shard_range(n_lines, r, world)
+        result.extend(unpack_labels(outs[r].cpu().numpy()[:hi - lo]))
+    return result
