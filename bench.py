@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--width", type=int, default=W_LINE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-lines", type=int, default=2)
+    ap.add_argument("--layers", action="store_true", help="print the per-layer device-time table to stderr")
     args = ap.parse_args()
 
     import torch
@@ -112,6 +113,9 @@ def main():
     dom_avg_ms = float(np.mean(dom_ms)) if dom_ms else float("nan")
     dom_tflops = FLOP_PER_COL_DOM * cols / (dom_avg_ms * 1e-3) / 1e12
     kernel_ms = float(sum(np.mean(v) for v in prof.values()))
+    if args.layers:
+        for name, v in prof.items():
+            print("%-24s %9.3f ms" % (name, float(np.mean(v))), file=sys.stderr)
     result = {
         "metric": "text-lines/sec (1x128x2000 synth) greedy decode",
         "value": round(lines_per_s, 3), "unit": "lines/s", "n_gpus": world, "steps": args.steps,

@@ -919,6 +919,12 @@ int64_t hctr_debug_activation(hctr_ctx* c, const char* name, float* out, int64_t
     else if (n == "stage2") { p = ws.x[3]; H = 16; C = 256; }
     else if (n == "stage3") { p = ws.x[4]; H = 8; C = 512; }
     else if (n == "stage4") { p = ws.headin; H = 4; C = 512; head = true; }
+    else if (n.size() == 4 && n[0] == 'p' && n[2] == '.' && n[1] >= '1' && n[1] <= '4' && n[3] >= '0' && n[3] <= '2') {
+        // raw rotating block buffer i of stage s ("p<s>.<i>"): what it holds depends on the block count
+        const int st = n[1] - '0', bi = n[3] - '0';
+        p = ws.p[st][bi]; H = kStageH[st]; C = kStagePlanes[st - 1];
+        if (!p) return fail(c, HCTR_ERR_ARG, "buffer %s not allocated", name);
+    }
     else return fail(c, HCTR_ERR_ARG, "unknown activation '%s'", name);
     const int64_t total = (int64_t)ws.B * C * H * ws.W;
     if (Cout) *Cout = C;

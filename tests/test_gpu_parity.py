@@ -1,12 +1,19 @@
 """GPU parity tests (-m gpu): the HIP engine, called through the C ABI, against the oracle and the
 committed golden fixtures (outputs of the real reference).
 
-Tolerances (fp16 storage / fp16 MFMA inputs / fp32 accumulate vs the fp32 CPU reference; the
-reference's own GPU mode is TF32, the same 10-bit mantissa):
-  logits      |err| <= LOGIT_RTOL * max|logit| + LOGIT_ATOL
-  argmax      bit-exact on every column whose reference top-2 margin exceeds 4x the measured error
-  decoded text exact when every column of the line is such a "safe" column (otherwise the line is
-              compared through its safe columns only and the count of ambiguous columns is bounded)
+Two floating-point checks, both with the tolerance written here:
+ (1) against the fp32 CPU reference (fixtures from the REAL reference, and the oracle). The engine
+     stores activations/weights in fp16 and accumulates in fp32 (the reference's own GPU mode is
+     TF32, the same 10-bit mantissa), so:
+       logits  |err| <= LOGIT_RTOL * max|logit| + LOGIT_ATOL
+       argmax  bit-exact on every column whose reference top-2 margin exceeds 2x the measured max
+               error (a flip needs err(top1) + err(top2) > margin), and >= MIN_AGREE overall
+       text    edit distance to the reference string bounded by the number of ambiguous columns;
+               exact when a line has none
+ (2) against the oracle with the engine's rounding points inserted (oracle.hctr_ref.forward_f16):
+     end to end |err| <= 0.008 * max|logit| (rounding-boundary flips still decorrelate two fp16
+     pipelines), but PER LAYER, from the engine's own activations, every element within one fp16
+     ulp and <= 3 % of elements differing at all; head logits within 2e-4 * max|logit|.
 Integer / index work (collapse, top-k order, candidate lists, beam search) is bit-exact.
 """
 import json
@@ -23,6 +30,7 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_RTOL = 0.01
 LOGIT_ATOL = 0.05
+MIN_AGREE = 0.95
 
 
 @pytest.fixture(scope="module")
@@ -38,9 +46,9 @@ def codec(pkg, synth, engine):
     return pkg.ctc_codec(synth.characters()).attach(engine)
 
 
-def _safe(ref, err):
+def _margin(ref):
     srt = np.sort(ref, axis=2)
-    return (srt[:, :, -1] - srt[:, :, -2]) > 4 * err
+    return srt[:, :, -1] - srt[:, :, -2]
 
 
 @pytest.mark.parametrize("name,seed,widths", [("b1w32", 21, [32]), ("b3w67u", 22, [67, 50, 33]),
@@ -56,14 +64,59 @@ def test_forward_matches_reference_fixture(engine, synth, name, seed, widths):
     err = float(np.abs(got[:, :, sub] - ref_sub).max())
     assert err <= tol, "max logit error %.4f > %.4f" % (err, tol)
     margin = g[name + "/top10_val"][:, :, 0] - g[name + "/top10_val"][:, :, 1]
-    safe = margin > 4 * err
-    assert safe.mean() > 0.9
-    assert np.array_equal(got.argmax(axis=2)[safe], g[name + "/argmax"][safe].astype(np.int64))
+    safe = margin > 2 * err
+    ref_arg = g[name + "/argmax"].astype(np.int64)
+    assert np.array_equal(got.argmax(axis=2)[safe], ref_arg[safe])
+    assert (got.argmax(axis=2) == ref_arg).mean() >= MIN_AGREE
     # activations along the trunk (debug taps) against the reference's
     for tap in ("stage0", "stage2", "stage4"):
         a = engine.debug_activation(tap, len(widths))[:, :8, :, :16]
         r = g[name + "/act/" + tap]
         assert np.abs(a - r).max() <= 0.02 * np.abs(r).max() + 0.02, tap
+
+
+@pytest.mark.parametrize("seed,widths", [(22, [67, 50, 33]), (24, [130, 130])])
+def test_forward_matches_f16_oracle(engine, synth, state_dict, seed, widths):
+    """Engine vs the oracle with the engine's rounding points inserted.
+
+    End to end the two fp16 pipelines still decorrelate (a one-ulp flip at a rounding boundary
+    perturbs ~1000 downstream sums per layer), so the end-to-end bound is only ~2x tighter than
+    against fp32. The TIGHT check is per layer: feed the engine's own tap into the oracle's next layer
+    and require the engine's next tap to match to one fp16 ulp on all but a sliver of elements."""
+    import torch
+    import torch.nn.functional as F
+    B = len(widths)
+    imgs = synth.make_line_images(B, max(widths), seed)
+    ref = hctr_ref.forward_f16(state_dict, synth.normalize_pad(imgs, widths)).numpy()
+    got = engine(imgs, widths=widths)
+    scale = float(np.abs(ref).max())
+    assert float(np.abs(got - ref).max()) <= 0.008 * scale
+    assert (got.argmax(axis=2) == ref.argmax(axis=2)).mean() >= 0.98
+
+    def close_ulp(a, r, what):
+        ulp = np.maximum(np.abs(r) * 2.0 ** -10, 3e-5)   # one fp16 ulp, floored by fp32 summation noise
+        diff = np.abs(a - r)
+        assert (diff <= ulp).all(), what
+        assert (diff > 0).mean() <= 0.03, what
+
+    # stem from the input image
+    x = torch.from_numpy(synth.normalize_pad(imgs, widths))
+    _, c01 = hctr_ref._conv_f16(state_dict, x, "cnn.conv0_1", "cnn.bn0_1", True, 1, half_weights=False)
+    close_ulp(engine.debug_activation("conv0_1", B), c01.numpy(), "conv0_1")
+    # conv0_2 + pool (MFMA conv, 64x256 tile) from the engine's own conv0_1
+    e01 = torch.from_numpy(engine.debug_activation("conv0_1", B))
+    _, s0 = hctr_ref._conv_f16(state_dict, e01, "cnn.conv0_2", "cnn.bn0_2", True, 1, pool=True)
+    close_ulp(engine.debug_activation("stage0", B), s0.numpy(), "conv0_2+pool")
+    # block1.1.conv1 (MFMA conv, 128x128 tile) from the engine's own block1.0 output (buffer p1.1)
+    b10 = torch.from_numpy(engine.debug_activation("p1.1", B))
+    _, t = hctr_ref._conv_f16(state_dict, b10, "cnn.block1.1.conv1", "cnn.block1.1.bn1", True, 1)
+    close_ulp(engine.debug_activation("p1.2", B), t.numpy(), "block1.1.conv1")
+    # head GEMM from the engine's own pooled features
+    f = torch.from_numpy(engine.debug_activation("stage4", B)).flatten(1, 2).permute(0, 2, 1)
+    w = torch.from_numpy(state_dict["linear.weight"]).half().float()
+    lg = F.linear(f, w, torch.from_numpy(state_dict["linear.bias"])).permute(1, 0, 2).numpy()
+    assert float(np.abs(got - lg).max()) <= 2e-4 * scale          # fp32 summation order only
+    assert (got.argmax(axis=2) == lg.argmax(axis=2)).mean() >= 0.999
 
 
 def test_input_paths_agree(engine, synth):
@@ -101,11 +154,12 @@ def test_long_line_against_reference_fixture(engine, codec, synth, name, seed, w
     tol = LOGIT_RTOL * float(np.abs(g[name + "/max"]).max()) + LOGIT_ATOL
     assert err <= tol
     margin = g[name + "/top10_val"][:, :, 0] - g[name + "/top10_val"][:, :, 1]
-    safe = margin > 4 * max(err, 1e-3)
+    safe = margin > 2 * max(err, 1e-3)
     amax = got.argmax(axis=2)
-    assert np.array_equal(amax[safe], g[name + "/argmax"][safe].astype(np.int64))
+    ref_arg = g[name + "/argmax"].astype(np.int64)
+    assert np.array_equal(amax[safe], ref_arg[safe])
+    assert (amax == ref_arg).mean() >= MIN_AGREE
     ambiguous = int((~safe).sum())
-    assert ambiguous <= 0.03 * w
     text = codec.labels_to_text(engine.greedy(imgs))[0]
     ref_text = strings[name]["greedy"][0]
     dist = ctc_ref.edit_distance(text, ref_text)
@@ -124,8 +178,10 @@ def test_config1_bundled_images(engine, codec):
         got = engine(img[None])
         err = float(np.abs(got.max(axis=2) - g[key + "/max"]).max())
         assert err <= LOGIT_RTOL * float(np.abs(g[key + "/max"]).max()) + LOGIT_ATOL, key
-        safe = g[key + "/top2_margin"] > 4 * max(err, 1e-3)
-        assert np.array_equal(got.argmax(axis=2)[safe], g[key + "/argmax"][safe].astype(np.int64)), key
+        safe = g[key + "/top2_margin"] > 2 * max(err, 1e-3)
+        ref_arg = g[key + "/argmax"].astype(np.int64)
+        assert np.array_equal(got.argmax(axis=2)[safe], ref_arg[safe]), key
+        assert (got.argmax(axis=2) == ref_arg).mean() >= MIN_AGREE, key
         text = codec.labels_to_text(engine.greedy(img[None]))[0]
         dist = ctc_ref.edit_distance(text, strings["c1_" + key]["greedy"][0])
         assert dist <= 2 * int((~safe).sum()), key

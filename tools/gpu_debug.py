@@ -43,3 +43,35 @@ agree = got.argmax(2) == ref.argmax(2)
 print("argmax agree %.4f; disagreeing margins: %s" % (agree.mean(), np.sort(margin[~agree])[:10]))
 got_f32 = model(x)
 print("u8-vs-f32 input paths max diff", np.abs(got_f32 - got).max())
+
+print("---- vs f16-emulating oracle ----")
+taps16 = {}
+ref16 = hctr_ref.forward_f16(sd, x, taps16).numpy()
+model(imgs, widths=widths)
+for name in ("conv0_1", "stage0", "stage1", "stage2", "stage3", "stage4"):
+    a = model.debug_activation(name, B)
+    r = taps16[name].numpy()
+    err = np.abs(a - r)
+    nz = err > 0
+    print("%-8s max|ref| %8.3f  max err %9.5f  mean err %.6f  frac differing %.4f  max rel(of differing) %.2e" %
+          (name, np.abs(r).max(), err.max(), err.mean(), nz.mean(),
+           (err[nz] / np.maximum(np.abs(r[nz]), 1e-3)).max() if nz.any() else 0), flush=True)
+err = np.abs(got - ref16)
+print("logits   max|ref| %8.3f  max err %8.4f  mean err %.5f  argmax agree %.4f" %
+      (np.abs(ref16).max(), err.max(), err.mean(), (got.argmax(2) == ref16.argmax(2)).mean()))
+
+print("---- stage-1 block buffers vs f16-emulating oracle ----")
+# after the forward: p1.1 = block1.0 output, p1.2 = block1.1.conv1 output, p1.0 = block1.1 output
+for buf, tap in (("p1.1", "block1.0"), ("p1.2", "block1.1.conv1"), ("p1.0", "block1.1")):
+    a = model.debug_activation(buf, B)
+    r = taps16[tap].numpy()
+    err = np.abs(a - r)
+    print("%-6s = %-16s max|ref| %7.3f max err %9.5f mean err %.6f frac differing %.4f" %
+          (buf, tap, np.abs(r).max(), err.max(), err.mean(), (err > 0).mean()), flush=True)
+# variant: what if the residual/downsample or the SE scale were different? test residual alone:
+a = model.debug_activation("p1.1", B)
+o = taps16["block1.0.conv2"].numpy(); sc = taps16["block1.0.scale"].numpy(); r = taps16["block1.0.res"].numpy()
+for label, val in (("o*sc+r (mul,add)", np.maximum(o * sc[:, :, None, None] + r, 0)),
+                   ("fma in f64 then f32", np.maximum((o.astype(np.float64) * sc[:, :, None, None] + r), 0).astype(np.float32))):
+    v16 = val.astype(np.float16).astype(np.float32)
+    print("  variant %-22s frac differing %.4f" % (label, (np.abs(a - v16) > 0).mean()))
