@@ -94,6 +94,7 @@ struct hctr_ctx {
     std::vector<void*> wallocs;
     Workspace ws;
     int64_t max_cols = kDefaultMaxCols;
+    bool big_tiles = true;
     // profiling
     bool profiling = false;
     std::vector<ProfEntry> prof;
@@ -357,14 +358,22 @@ struct ActDesc {            // a padded NHWC activation
     int H, C;
 };
 
+// Block tile per layer: 256x256 (8 waves) halves the bytes staged per MFMA, so it is used wherever
+// the layer shape allows (Cout % 256 == 0, H % 16 == 0: stages 2 and 3 = 82 % of the FLOPs).
+ConvTile pick_tile(const hctr_ctx* c, const ConvW& cw, int H) {
+    if (cw.cout == 64) return TILE_64x256;
+    if (c->big_tiles && cw.coutPad % 256 == 0 && H % 16 == 0) return TILE_256x256;
+    return TILE_128x128;
+}
+
 int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc in, half_t* out, int outH,
              bool relu, bool pool, float* se_part, bool to_head) {
     const Workspace& ws = c->ws;
     ConvArgs a{};
     a.x = in.p; a.w = cw.w; a.bias = cw.bias; a.y = out; a.se_part = se_part;
     a.H = in.H; a.W = ws.W; a.Cin = cw.cin; a.Cout = cw.cout; a.CoutPad = cw.coutPad;
-    const ConvTile tile = cw.cout == 64 ? TILE_64x256 : TILE_128x128;
-    const int rows = tile == TILE_64x256 ? 16 : 8;
+    const ConvTile tile = pick_tile(c, cw, in.H);
+    const int rows = conv_tile_rows(tile);
     if (in.H % rows != 0 || cw.cin % kBK != 0)
         return fail(c, HCTR_ERR_ARG, "conv %s: H=%d or Cin=%d not tileable", name, in.H, cw.cin);
     a.tilesW = (ws.W + kTileW - 1) / kTileW;
@@ -382,7 +391,7 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
     }
     a.relu = relu; a.pool = pool;
     a.mtiles = ws.B * a.tilesH * a.tilesW;
-    a.ntiles = cw.coutPad / (tile == TILE_64x256 ? 64 : 128);
+    a.ntiles = cw.coutPad / conv_tile_couts(tile);
     pf.begin(name);
     HIP_TRY(c, launch_conv(a, tile, cw.taps, false, c->stream));
     pf.end();
@@ -397,7 +406,7 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
     TRY(run_conv(c, pf, (name + ".conv1").c_str(), bw.conv1, in, t, H, true, false, nullptr, false));
     TRY(run_conv(c, pf, (name + ".conv2").c_str(), bw.conv2, ActDesc{t, H, planes}, o, H, false, false,
                  ws.se_part, false));
-    const int tiles = (H / 8) * ((ws.W + kTileW - 1) / kTileW);
+    const int tiles = (H / conv_tile_rows(pick_tile(c, bw.conv2, H))) * ((ws.W + kTileW - 1) / kTileW);
     pf.begin((name + ".se_fc").c_str());
     HIP_TRY(c, launch_se_fc(ws.se_part, tiles, bw.se.w1, bw.se.w2, ws.se_scale, ws.B, planes,
                             1.0f / ((float)H * (float)ws.W), c->stream));
@@ -454,9 +463,11 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths) {
     a.x = ws.headin; a.w = c->head.w; a.bias = c->head.bias; a.y = ws.logits;
     a.Cin = kFeat; a.Cout = c->num_classes; a.CoutPad = c->cpad;
     a.M = (int64_t)ws.B * ws.W; a.ldo = c->cpad;
-    a.mtiles = (int)((a.M + 127) / 128); a.ntiles = c->cpad / 128;
+    const ConvTile htile = (c->big_tiles && c->cpad % 256 == 0) ? TILE_256x256 : TILE_128x128;
+    const int hbm = htile == TILE_256x256 ? 256 : 128;
+    a.mtiles = (int)((a.M + hbm - 1) / hbm); a.ntiles = c->cpad / hbm;
     pf.begin("head.linear");
-    HIP_TRY(c, launch_conv(a, TILE_128x128, 1, true, c->stream));
+    HIP_TRY(c, launch_conv(a, htile, 1, true, c->stream));
     pf.end();
     return HCTR_OK;
 }
@@ -518,12 +529,13 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
     hctr_ctx* c = new hctr_ctx();
     c->device = device;
     c->num_classes = num_classes;
-    c->cpad = (num_classes + 127) / 128 * 128;
+    c->cpad = (num_classes + 255) / 256 * 256;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
         return fail(nullptr, HCTR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    if (const char* bt = getenv("HCTR_BIG_TILES")) c->big_tiles = atoi(bt) != 0;
     if (const char* mc = getenv("HCTR_MAX_COLS")) {
         const long long v = atoll(mc);
         if (v > 0) c->max_cols = v;

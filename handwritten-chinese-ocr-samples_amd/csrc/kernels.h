@@ -35,7 +35,9 @@ struct ConvArgs {
 };
 
 // tile configurations: (couts x pixels) per 256-thread block
-enum ConvTile { TILE_64x256 = 0, TILE_128x128 = 1 };
+enum ConvTile { TILE_64x256 = 0, TILE_128x128 = 1, TILE_256x256 = 2 };
+inline int conv_tile_rows(ConvTile t) { return t == TILE_128x128 ? 8 : 16; }
+inline int conv_tile_couts(ConvTile t) { return t == TILE_64x256 ? 64 : (t == TILE_128x128 ? 128 : 256); }
 
 hipError_t launch_conv(const ConvArgs& a, ConvTile tile, int taps, bool linear_f32, hipStream_t s);
 size_t conv_lds_bytes(ConvTile tile);

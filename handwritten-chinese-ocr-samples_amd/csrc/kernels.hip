@@ -22,7 +22,8 @@ typedef void __attribute__((address_space(3))) * lptr_t;
 // GEMM view: D[cout][pixel] = sum_{tap,cin} Wt[tap][cout][cin] * X[pixel + tap][cin]
 //   MFMA A operand = weights (rows = couts), B operand = pixels (cols), so every lane ends up with
 //   16 consecutive couts of one pixel = one 32-byte NHWC store.
-// Block = WN x WM waves; each wave owns 64 couts x 64 pixels (4x4 MFMA tiles, 64 fp32 acc regs).
+// Block = WN x WM waves; each wave owns JT*16 couts x 64 pixels (JT x 4 MFMA tiles): 64 couts
+//   (64 fp32 acc regs) for the 64x256 and 128x128 block tiles, 128 couts for the 256x256 tile.
 //   conv mode: a wave's 64 pixels are a 4-row x 16-column patch; MFMA column c = image column,
 //   pixel repeat n = image row, so the (2,1) max-pool pairs repeats (0,1),(2,3) inside a lane.
 // K loop: taps x (Cin/64) steps; both operand tiles ([rows][64 cin] fp16 = 128-byte rows) are
@@ -32,10 +33,11 @@ typedef void __attribute__((address_space(3))) * lptr_t;
 //   applied on the global SOURCE address and again on the ds_read_b128 address (conflict-free for
 //   the 16x16x32 operand pattern; cdna guide rule 21).
 // -------------------------------------------------------------------------------------------
-template <int WN, int WM, int TAPS, bool LINEAR>
+template <int WN, int WM, int JT, int TAPS, bool LINEAR>
 __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int NT = WN * WM * 64;
-    constexpr int BN = WN * 64, BM = WM * 64;
+    constexpr int WC = JT * 16;          // couts per wave (64 or 128)
+    constexpr int BN = WN * WC, BM = WM * 64;
     constexpr int NIW = BN * 8 / NT;     // 16-byte chunks of the weight tile per thread
     constexpr int NIX = BM * 8 / NT;     // ... of the pixel tile
     constexpr int TILE_BYTES = (BN + BM) * 128;
@@ -68,29 +70,31 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
     }
     const int cin = a.Cin;
 
-    // ---- per-thread staging sources -------------------------------------------------------
-    const char* xsrc[NIX];
-    const char* wsrc[NIW];
+    // ---- per-thread staging sources: uniform base (SGPRs) + 32-bit per-lane byte offset ----
+    const char* xbase;
+    if (LINEAR) xbase = (const char*)(a.x + (int64_t)mt * BM * cin);
+    else xbase = (const char*)(a.x + img * a.in_sb);
+    const char* wbase = (const char*)(a.w + (int64_t)n0 * cin);
+    uint32_t xoff[NIX], woff[NIW];
 #pragma unroll
     for (int i = 0; i < NIX; ++i) {
         const int g = (wv * NIX + i) * 64 + lane;
         const int row = g >> 3, cp = (g & 7) ^ (row & 7);
         if (LINEAR) {
-            int64_t m = (int64_t)mt * BM + row;
-            if (m >= a.M) m = a.M - 1;
-            xsrc[i] = (const char*)(a.x + m * cin) + cp * 16;
+            int64_t rem = a.M - (int64_t)mt * BM;            // rows left in this tile (>= 1)
+            const int r = (int64_t)row < rem ? row : (int)rem - 1;
+            xoff[i] = (uint32_t)r * (uint32_t)cin * 2u + cp * 16;
         } else {
             const int h = th * (4 * WM) + (row >> 6) * 4 + ((row >> 4) & 3);
             const int w = tw * kTileW + (row & 15);
-            xsrc[i] = (const char*)(a.x + img * a.in_sb + (int64_t)(h + 1) * a.in_sh +
-                                    (int64_t)(w + 1) * cin) + cp * 16;
+            xoff[i] = ((uint32_t)(h + 1) * (uint32_t)a.in_sh + (uint32_t)(w + 1) * (uint32_t)cin) * 2u + cp * 16;
         }
     }
 #pragma unroll
     for (int i = 0; i < NIW; ++i) {
         const int g = (wv * NIW + i) * 64 + lane;
         const int row = g >> 3, cp = (g & 7) ^ (row & 7);
-        wsrc[i] = (const char*)(a.w + (int64_t)(n0 + row) * cin) + cp * 16;
+        woff[i] = (uint32_t)row * (uint32_t)cin * 2u + cp * 16;
     }
 
     const int kc_steps = cin / kBK;
@@ -105,19 +109,21 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
             xo += ((int64_t)dy * a.in_sh + (int64_t)dx * cin) * 2;
         }
         const int64_t wo = ((int64_t)tap * a.CoutPad * cin + (int64_t)kc * kBK) * 2;
+        const char* xs = xbase + xo;
+        const char* wsrc = wbase + wo;
         char* wdst = smem + buf * TILE_BYTES + (wv * NIW) * 1024;
         char* xdst = smem + buf * TILE_BYTES + BN * 128 + (wv * NIX) * 1024;
 #pragma unroll
         for (int i = 0; i < NIW; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + wo), (lptr_t)(wdst + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + woff[i]), (lptr_t)(wdst + i * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < NIX; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + xo), (lptr_t)(xdst + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(xs + xoff[i]), (lptr_t)(xdst + i * 1024), 16, 0, 0);
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[JT][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < JT; ++j)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -132,34 +138,39 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (k + 1 < nk) stage(k + 1, (k + 1) & 1);
-        const char* wt = smem + (k & 1) * TILE_BYTES + (wn * 64) * 128;
+        const char* wt = smem + (k & 1) * TILE_BYTES + (wn * WC) * 128;
         const char* xt = smem + (k & 1) * TILE_BYTES + BN * 128 + (wm * 64) * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int fo = ks ? foff1 : foff0;
-            f16x8 af[4], bf[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) af[j] = *(const f16x8*)(wt + j * 2048 + fo);
+            f16x8 af[JT], bf[4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) bf[n] = *(const f16x8*)(xt + n * 2048 + fo);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < JT; ++j) af[j] = *(const f16x8*)(wt + j * 2048 + fo);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
                     acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], bf[n], acc[j][n], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
-    // lane (q, c): couts n0 + wn*64 + q*16 + j*4 + i, pixel column c, pixel repeat n.
+    // lane (q, c): for cout block cb (64 couts) the lane owns couts q*16 + jj*4 + i (jj = j & 3),
+    // i.e. 16 consecutive couts, of pixel column c and pixel repeat n.
     const int c = lane & 15;
-    const int co0 = n0 + wn * 64 + q * 16;
-    float bias[16];
+    const int cw0 = n0 + wn * WC + q * 16;      // + cb*64 + jj*4 + i
+
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const f32x4 b4 = *(const f32x4*)(a.bias + co0 + j * 4);
+    for (int j = 0; j < JT; ++j) {
+        const f32x4 b4 = *(const f32x4*)(a.bias + cw0 + (j >> 2) * 64 + (j & 3) * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bias[j * 4 + i] = b4[i];
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][n][i] += b4[i];
     }
 
     if (LINEAR) {
@@ -168,14 +179,9 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
         for (int n = 0; n < 4; ++n) {
             const int64_t m = (int64_t)mt * BM + wm * 64 + n * 16 + c;
             if (m < a.M) {
-                float* o = out + m * a.ldo + co0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 v;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = acc[j][n][i] + bias[j * 4 + i];
-                    *(f32x4*)(o + j * 4) = v;
-                }
+                for (int j = 0; j < JT; ++j)
+                    *(f32x4*)(out + m * a.ldo + cw0 + (j >> 2) * 64 + (j & 3) * 4) = acc[j][n];
             }
         }
         return;
@@ -183,12 +189,6 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
 
     const int w = tw * kTileW + c;
     const bool wvalid = w < a.W;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][n][i] += bias[j * 4 + i];
 
     if (a.se_part != nullptr) {
         // per-(image, channel) sums over this block's valid pixels, fixed reduction order
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
         __syncthreads();                       // main-loop LDS no longer needed
         float* red = (float*)smem;             // [WM][BN]
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < JT; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float s = wvalid ? (acc[j][0][i] + acc[j][1][i]) + (acc[j][2][i] + acc[j][3][i]) : 0.f;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
                 s += __shfl_xor(s, 2);
                 s += __shfl_xor(s, 4);
                 s += __shfl_xor(s, 8);
-                if (c == 0) red[wm * BN + wn * 64 + q * 16 + j * 4 + i] = s;
+                if (c == 0) red[wm * BN + wn * WC + (j >> 2) * 64 + q * 16 + (j & 3) * 4 + i] = s;
             }
         __syncthreads();
         if (tid < BN) {
@@ -219,50 +219,58 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
     half_t* out = (half_t*)a.y;
     if (w < a.out_wlimit) {
         const int hbase = th * (4 * WM) + wm * 4;
+        half_t* obase = out + a.out_off + img * a.out_sb + (int64_t)w * a.out_sw + cw0;
         if (a.pool) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                f16x8 lo, hi;
+                half_t* o = obase + (int64_t)((hbase >> 1) + p) * a.out_sh;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float v = fmaxf(acc[e >> 2][2 * p][e & 3], acc[e >> 2][2 * p + 1][e & 3]);
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (!wvalid) v = 0.f;
-                    if (e < 8) lo[e] = (half_t)v; else hi[e - 8] = (half_t)v;
+                for (int cb = 0; cb < JT / 4; ++cb) {
+                    f16x8 lo, hi;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = fmaxf(acc[cb * 4 + (e >> 2)][2 * p][e & 3], acc[cb * 4 + (e >> 2)][2 * p + 1][e & 3]);
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        if (!wvalid) v = 0.f;
+                        if (e < 8) lo[e] = (half_t)v; else hi[e - 8] = (half_t)v;
+                    }
+                    *(f16x8*)(o + cb * 64) = lo;
+                    *(f16x8*)(o + cb * 64 + 8) = hi;
                 }
-                const int ho = (hbase >> 1) + p;
-                half_t* o = out + a.out_off + img * a.out_sb + (int64_t)ho * a.out_sh +
-                            (int64_t)w * a.out_sw + co0;
-                *(f16x8*)o = lo;
-                *(f16x8*)(o + 8) = hi;
             }
         } else {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                f16x8 lo, hi;
+                half_t* o = obase + (int64_t)(hbase + n) * a.out_sh;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float v = acc[e >> 2][n][e & 3];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (!wvalid) v = 0.f;
-                    if (e < 8) lo[e] = (half_t)v; else hi[e - 8] = (half_t)v;
+                for (int cb = 0; cb < JT / 4; ++cb) {
+                    f16x8 lo, hi;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = acc[cb * 4 + (e >> 2)][n][e & 3];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        if (!wvalid) v = 0.f;
+                        if (e < 8) lo[e] = (half_t)v; else hi[e - 8] = (half_t)v;
+                    }
+                    *(f16x8*)(o + cb * 64) = lo;
+                    *(f16x8*)(o + cb * 64 + 8) = hi;
                 }
-                half_t* o = out + a.out_off + img * a.out_sb + (int64_t)(hbase + n) * a.out_sh +
-                            (int64_t)w * a.out_sw + co0;
-                *(f16x8*)o = lo;
-                *(f16x8*)(o + 8) = hi;
             }
         }
     }
 }
 
 size_t conv_lds_bytes(ConvTile tile) {
-    return tile == TILE_64x256 ? 2 * (64 + 256) * 128 : 2 * (128 + 128) * 128;
+    switch (tile) {
+        case TILE_64x256: return 2 * (64 + 256) * 128;
+        case TILE_256x256: return 2 * (256 + 256) * 128;
+        default: return 2 * (128 + 128) * 128;
+    }
 }
 
-template <int WN, int WM, int TAPS, bool LINEAR>
+template <int WN, int WM, int JT, int TAPS, bool LINEAR>
 static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
-    auto kern = conv_mfma_kernel<WN, WM, TAPS, LINEAR>;
+    auto kern = conv_mfma_kernel<WN, WM, JT, TAPS, LINEAR>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -276,11 +284,18 @@ static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
 
 hipError_t launch_conv(const ConvArgs& a, ConvTile tile, int taps, bool linear_f32, hipStream_t s) {
     const size_t lds = conv_lds_bytes(tile);
-    if (linear_f32) return launch_conv_t<2, 2, 1, true>(a, lds, s);
-    if (tile == TILE_64x256) {
-        return taps == 9 ? launch_conv_t<1, 4, 9, false>(a, lds, s) : launch_conv_t<1, 4, 1, false>(a, lds, s);
+    if (linear_f32) {
+        return tile == TILE_256x256 ? launch_conv_t<2, 4, 8, 1, true>(a, lds, s)
+                                    : launch_conv_t<2, 2, 4, 1, true>(a, lds, s);
     }
-    return taps == 9 ? launch_conv_t<2, 2, 9, false>(a, lds, s) : launch_conv_t<2, 2, 1, false>(a, lds, s);
+    switch (tile) {
+        case TILE_64x256:
+            return taps == 9 ? launch_conv_t<1, 4, 4, 9, false>(a, lds, s) : launch_conv_t<1, 4, 4, 1, false>(a, lds, s);
+        case TILE_256x256:
+            return taps == 9 ? launch_conv_t<2, 4, 8, 9, false>(a, lds, s) : launch_conv_t<2, 4, 8, 1, false>(a, lds, s);
+        default:
+            return taps == 9 ? launch_conv_t<2, 2, 4, 9, false>(a, lds, s) : launch_conv_t<2, 2, 4, 1, false>(a, lds, s);
+    }
 }
 
 // -------------------------------------------------------------------------------------------

@@ -93,24 +93,37 @@ def test_forward_matches_f16_oracle(engine, synth, state_dict, seed, widths):
     assert float(np.abs(got - ref).max()) <= 0.008 * scale
     assert (got.argmax(axis=2) == ref.argmax(axis=2)).mean() >= 0.98
 
-    def close_ulp(a, r, what):
-        ulp = np.maximum(np.abs(r) * 2.0 ** -10, 3e-5)   # one fp16 ulp, floored by fp32 summation noise
+    def check_layer(tap_in, tap_out, ck, bk, pool, what, half_weights=True, x_in=None):
+        """engine[tap_out] vs oracle layer applied to engine[tap_in]. Bound per element:
+        one fp16 ulp of the result + accumulation noise, which scales with the magnitude of the
+        summed terms (sum |w||x|), not of the result (cancellation-heavy channels). Measured on
+        gfx950: v_mfma_f32_16x16x32_f16 accumulation error grows ~linearly with K (about
+        K * 2^-24 * sum|w||x| / K worst case, e.g. 7e-5 at K=576, sum|terms|~20), hence 2^-16."""
+        xin = x_in if x_in is not None else torch.from_numpy(engine.debug_activation(tap_in, B))
+        _, r = hctr_ref._conv_f16(state_dict, xin, ck, bk, True, 1, pool=pool, half_weights=half_weights)
+        w, bias = hctr_ref._fold(state_dict, ck, bk, half_weights)
+        mag = F.conv2d(xin.abs(), w.abs(), bias.abs(), padding=1)
+        if pool:
+            mag = F.max_pool2d(mag, (2, 1), (2, 1))
+        r, mag = r.numpy(), mag.numpy()
+        a = engine.debug_activation(tap_out, B)
+        tol = np.abs(r) * 2.0 ** -10 + mag * 2.0 ** -16 + 1e-6
         diff = np.abs(a - r)
-        assert (diff <= ulp).all(), what
+        assert (diff <= tol).all(), (what, float((diff / tol).max()))
         assert (diff > 0).mean() <= 0.03, what
 
-    # stem from the input image
     x = torch.from_numpy(synth.normalize_pad(imgs, widths))
-    _, c01 = hctr_ref._conv_f16(state_dict, x, "cnn.conv0_1", "cnn.bn0_1", True, 1, half_weights=False)
-    close_ulp(engine.debug_activation("conv0_1", B), c01.numpy(), "conv0_1")
-    # conv0_2 + pool (MFMA conv, 64x256 tile) from the engine's own conv0_1
-    e01 = torch.from_numpy(engine.debug_activation("conv0_1", B))
-    _, s0 = hctr_ref._conv_f16(state_dict, e01, "cnn.conv0_2", "cnn.bn0_2", True, 1, pool=True)
-    close_ulp(engine.debug_activation("stage0", B), s0.numpy(), "conv0_2+pool")
-    # block1.1.conv1 (MFMA conv, 128x128 tile) from the engine's own block1.0 output (buffer p1.1)
-    b10 = torch.from_numpy(engine.debug_activation("p1.1", B))
-    _, t = hctr_ref._conv_f16(state_dict, b10, "cnn.block1.1.conv1", "cnn.block1.1.bn1", True, 1)
-    close_ulp(engine.debug_activation("p1.2", B), t.numpy(), "block1.1.conv1")
+    check_layer(None, "conv0_1", "cnn.conv0_1", "cnn.bn0_1", False, "stem", half_weights=False, x_in=x)
+    # MFMA conv, 64x256 tile, fused pool: from the engine's own conv0_1
+    check_layer("conv0_1", "stage0", "cnn.conv0_2", "cnn.bn0_2", True, "conv0_2+pool")
+    # MFMA conv, 128x128 tile: block1.1.conv1 from the engine's own block1.0 output (buffer p1.1)
+    check_layer("p1.1", "p1.2", "cnn.block1.1.conv1", "cnn.block1.1.bn1", False, "block1.1.conv1")
+    # MFMA conv, 256x256 tile: block2.3.conv1 (p2.0) from block2.2's output (p2.2); block3.4.conv1
+    # (p3.2) from block3.3's output (p3.1)  [buffer rotation: engine.cpp run_forward]
+    check_layer("p2.2", "p2.0", "cnn.block2.3.conv1", "cnn.block2.3.bn1", False, "block2.3.conv1")
+    check_layer("p3.1", "p3.2", "cnn.block3.4.conv1", "cnn.block3.4.bn1", False, "block3.4.conv1")
+    # fused pool + head-input layout: conv4+pool from block4.0's output (p4.1)
+    check_layer("p4.1", "stage4", "cnn.conv4", "cnn.bn4", True, "conv4+pool")
     # head GEMM from the engine's own pooled features
     f = torch.from_numpy(engine.debug_activation("stage4", B)).flatten(1, 2).permute(0, 2, 1)
     w = torch.from_numpy(state_dict["linear.weight"]).half().float()
