@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Evaluation / inference CLI for the MI355X hctr engine, flag-compatible with the reference's
+``test.py`` (flags ``test.py:24-106``; flow ``test.py:109-201``; ``-bm`` CER loop ``test.py:230-306``;
+``-gs`` grid search ``test.py:347-382``).
+
+Differences from the reference, by design:
+  * the model and codec are the engine-backed drop-ins (``hctr_amd``); ``--gpu`` defaults to 0 because
+    there is no CPU execution path;
+  * batches go through the fused device path (uint8 images + widths -> labels); the 29 kB-per-column
+    logits never reach the host;
+  * images are read with PIL (cv2 is not a dependency); keep-ratio resize to height 128 uses bilinear
+    interpolation - pixel parity with cv2.INTER_AREA (test.py:204-216) is unpinned;
+  * ``-f synthetic[:seed]`` loads the package's deterministic synthetic checkpoint (no checkpoint files
+    are bundled with the reference), and then the vocabulary defaults to the synthetic one;
+  * ``-kp zero|toy`` selects a built-in language model for beam search when kenlm is not installed.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+IMG_EXT = (".jpg", ".jpeg", ".png", ".bmp")
+
+
+def build_argparser():
+    p = argparse.ArgumentParser(description="hctr inference on MI355X (reference test.py flags)")
+    a = p.add_argument_group("Options")
+    a.add_argument("-m", "--model-type", dest="model_type", type=str, required=True, choices=["hctr"])
+    a.add_argument("-f", "--model-file", dest="model_file", type=str, required=True,
+                   help="checkpoint (.pth.tar with 'state_dict') or 'synthetic[:seed]'")
+    a.add_argument("-i", "--input", dest="input", type=str, required=True, help="image file or folder")
+    a.add_argument("-b", "--batch-size", dest="batch_size", type=int, metavar="N", default=1)
+    a.add_argument("--gpu", type=int, default=0)
+    a.add_argument("-bm", "--benchmark-mode", dest="benchmark_mode", action="store_true")
+    a.add_argument("-dm", "--decode-method", dest="decode_method", type=str, default="beam-search",
+                   choices=["greedy-search", "beam-search"])
+    a.add_argument("-ss", "--skip-search", dest="skip_search", action="store_true")
+    a.add_argument("-kp", "--kenlm-path", dest="kenlm_path", type=str, default="")
+    a.add_argument("-utp", "--use-tfm-pred", dest="use_tfm_pred", action="store_true")
+    a.add_argument("-tp", "--transformer-path", dest="tfm_path", type=str, default="")
+    a.add_argument("-uts", "--use-tfm-score", dest="use_tfm_score", action="store_true")
+    a.add_argument("-uov", "--use-openvino", dest="use_openvino", action="store_true")
+    a.add_argument("-bs", "--beam-size", dest="beam_size", type=int, default=10)
+    a.add_argument("-sd", "--search-depth", dest="search_depth", type=int, default=10)
+    a.add_argument("-lp", "--lm-panelty", dest="lm_panelty", type=float, default=0.8)
+    a.add_argument("-lb", "--len-bonus", dest="len_bonus", type=float, default=4.8)
+    a.add_argument("-jw", "--workers", type=int, metavar="N", default=4)
+    a.add_argument("-tv", "--test-verbose", dest="test_verbose", action="store_true")
+    a.add_argument("-pf", "--print-freq", dest="print_freq", type=int, metavar="N", default=100)
+    a.add_argument("-gs", "--grid-search", action="store_true")
+    a.add_argument("-al", "--alpha-lower", type=float, default=0.7)
+    a.add_argument("-au", "--alpha-upper", type=float, default=1.1)
+    a.add_argument("-ac", "--alpha-count", type=int, default=10)
+    a.add_argument("-bl", "--beta-lower", type=float, default=4.2)
+    a.add_argument("-bu", "--beta-upper", type=float, default=6.6)
+    a.add_argument("-bc", "--beta-count", type=int, default=25)
+    return p
+
+
+def find_characters(input_path, synthetic):
+    """chars_list.txt discovery chain of test.py:315-332; synthetic vocabulary as the last resort."""
+    cands = []
+    if input_path:
+        cands.append(os.path.join(os.path.dirname(input_path.rstrip("/")), "chars_list.txt"))
+    cands += ["./data/handwritten_ctr_data/chars_list.txt", "./data/hwdb2.0/chars_list.txt",
+              "./data/demo_data/chars_list.txt"]
+    for c in cands:
+        if os.path.isfile(c):
+            with open(c, "r") as f:
+                return "".join(line.strip("\n") for line in f.readlines())
+    if synthetic:
+        import hctr_amd
+        return hctr_amd.synth.characters()
+    raise FileNotFoundError("chars_list.txt not found (looked in: %s)" % ", ".join(cands))
+
+
+def read_resize_image(path, height):
+    from PIL import Image
+    im = Image.open(path).convert("L")
+    tw = max(1, int(height * (float(im.size[0]) / float(im.size[1]))))
+    return np.asarray(im.resize((tw, height), Image.BILINEAR), dtype=np.uint8)
+
+
+def list_inputs(path):
+    if os.path.isfile(path):
+        return [path]
+    return [os.path.join(path, n) for n in sorted(os.listdir(path)) if n.lower().endswith(IMG_EXT)]
+
+
+def pad_batch(images):
+    """[B,128,maxW] uint8 + widths; the engine applies NormalizePAD's replicate pad (utils/dataset.py:83-93)."""
+    widths = np.array([im.shape[1] for im in images], dtype=np.int32)
+    out = np.zeros((len(images), 128, int(widths.max())), dtype=np.uint8)
+    for i, im in enumerate(images):
+        out[i, :, :im.shape[1]] = im
+    return out, widths
+
+
+def edit_distance(a, b):
+    if len(a) < len(b):
+        a, b = b, a
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def build(args):
+    import hctr_amd
+    synthetic = args.model_file.startswith("synthetic")
+    if not synthetic and not os.path.isfile(args.model_file):
+        raise FileNotFoundError("No model file found at: {}".format(args.model_file))
+    if not (os.path.isdir(args.input) or os.path.isfile(args.input)):
+        raise FileNotFoundError("Input is not found, expected file or folder.")
+    characters = find_characters(args.input, synthetic)
+    num_classes = 1 + len(characters) + 1                      # test.py:334
+    print("Character vocabulary: {}, Model output classes: {}".format(len(characters), num_classes))
+    model = hctr_amd.hctr_model(num_classes=num_classes)
+    codec = hctr_amd.ctc_codec(characters)
+    print("Use GPU: {} for testing".format(args.gpu))
+    model = model.cuda(args.gpu)
+    print("=> loading model file: {}".format(args.model_file))
+    if synthetic:
+        seed = int(args.model_file.split(":")[1]) if ":" in args.model_file else 0
+        sd = hctr_amd.synth.make_state_dict(num_classes, seed=seed)
+    else:
+        import torch
+        ckpt = torch.load(args.model_file, map_location="cpu", weights_only=True)
+        sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+    model.load_state_dict(sd)
+    model.eval()
+    codec.attach(model)
+    if args.decode_method == "beam-search":
+        codec.set_beam_search(args.skip_search, ngram_path=args.kenlm_path or "zero", tfm_path=args.tfm_path,
+                              lm_panelty=args.lm_panelty, len_bonus=args.len_bonus, beam_size=args.beam_size,
+                              search_depth=args.search_depth, use_tfm_score=args.use_tfm_score,
+                              use_tfm_pred=args.use_tfm_pred, use_openvino=args.use_openvino)
+    return model, codec
+
+
+def recognise(model, codec, imgs, widths):
+    if codec.use_beam_search and not codec.use_tfm_pred:
+        fe = model.beam_frontend(imgs, k=min(codec.search_depth, model.noutput), widths=widths,
+                                 want_candidates=codec.skip_search)
+        return codec.decode_frontend(fe)
+    if codec.use_beam_search:                                   # LM-proposed candidates need full log-probs
+        return codec.decode(model(imgs, widths=widths))
+    return codec.labels_to_text(model.greedy(imgs, widths=widths))
+
+
+def test(args):
+    model, codec = build(args)
+    if args.benchmark_mode:
+        return benchmark(model, codec, args)
+    paths = list_inputs(args.input)
+    images = [read_resize_image(p, model.img_height) for p in paths]
+    for i in range(len(images) // args.batch_size):
+        print("batch {} is being processed...".format(i))
+        imgs, widths = pad_batch(images[i * args.batch_size:(i + 1) * args.batch_size])
+        t0 = time.time()
+        result = recognise(model, codec, imgs, widths)
+        dt = time.time() - t0
+        print("max_width: {}, throughput: {} ms/img".format(int(widths.max()), dt / args.batch_size * 1000))
+        print("predicted results: {}".format(result))
+    return None
+
+
+def benchmark(model, codec, args):
+    """CER over ``<input>/test_img_id_gt.txt`` ('<image name>,<text>' per line, images under
+    ``<input>/test/``; utils/dataset.py:31-37)."""
+    if not os.path.isdir(args.input):
+        raise AssertionError("Input should be a folder under benchmark mode.")
+    gt = os.path.join(args.input, "test_img_id_gt.txt")
+    items = []
+    with open(gt, "r", encoding="utf-8") as f:
+        for line in f.readlines():
+            parts = line.strip("\n").split(",", 1)
+            if len(parts) != 2 or not parts[1]:
+                continue
+            for cand in (os.path.join(args.input, "test", parts[0]), os.path.join(args.input, parts[0])):
+                hit = [cand + e for e in ("",) + IMG_EXT if os.path.isfile(cand + e)]
+                if hit and os.stat(hit[0]).st_size > 0:
+                    items.append((hit[0], parts[1]))
+                    break
+    items = items[:args.batch_size * (len(items) // args.batch_size)]      # ImageDataset.__len__
+    total = nchars = 0
+    cer = 0.0
+    t_all = time.time()
+    for i in range(0, len(items), args.batch_size):
+        chunk = items[i:i + args.batch_size]
+        images = [read_resize_image(n, model.img_height) for n, _ in chunk]
+        imgs, widths = pad_batch(images)
+        t0 = time.time()
+        result = recognise(model, codec, imgs, widths)
+        for j, (pre, (_, tru)) in enumerate(zip(result, chunk)):
+            if args.test_verbose:
+                print("TEST [{0}/{1}]\nTEST PRE {2}\nTEST TRU {3}".format(j, i // args.batch_size, pre, tru))
+            total += edit_distance(pre, tru)
+            nchars += len(tru)
+        if nchars == 0:
+            raise ValueError("Number of label characters should not be 0.")
+        cer = total * 1.0 / nchars
+        if (i // args.batch_size) % args.print_freq == 0:
+            print("TEST: [{0}/{1}]\tTime {2:.3f}\tErr {3:.4f}".format(i // args.batch_size,
+                  (len(items) + args.batch_size - 1) // args.batch_size, time.time() - t0, cer))
+    print("Total Test CER: {} ({:.1f}s)".format(cer, time.time() - t_all))
+    return cer
+
+
+def main():
+    args = build_argparser().parse_args()
+    if not args.grid_search:
+        test(args)
+        return
+    if not args.benchmark_mode:
+        raise AssertionError(args.benchmark_mode)
+    best, best_params = 1.0, (0, 0)
+    for a in np.linspace(args.alpha_lower, args.alpha_upper, args.alpha_count):
+        for b in np.linspace(args.beta_lower, args.beta_upper, args.beta_count):
+            print("searching with a:{}, b:{}, min params:{}, min cer:{}".format(a, b, best_params, best))
+            args.lm_panelty, args.len_bonus = a, b
+            cer = test(args)
+            if cer < best:
+                best, best_params = cer, (a, b)
+    print("min params:{}, min cer: {}".format(best_params, best))
+
+
+if __name__ == "__main__":
+    main()
