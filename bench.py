@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-lines", type=int, default=2)
     ap.add_argument("--layers", action="store_true", help="print the per-layer device-time table to stderr")
+    ap.add_argument("--layer-file", default="", help="write the per-step launch order (layer names) to this file")
     args = ap.parse_args()
 
     import torch
@@ -113,9 +114,23 @@ def main():
     dom_avg_ms = float(np.mean(dom_ms)) if dom_ms else float("nan")
     dom_tflops = FLOP_PER_COL_DOM * cols / (dom_avg_ms * 1e-3) / 1e12
     kernel_ms = float(sum(np.mean(v) for v in prof.values()))
+    # HBM-side traffic of the dominant kernel per launch: rocprofv3 PMC passes of this same command
+    # (tools/profile_rocprof.sh: FETCH_SIZE and WRITE_SIZE in separate runs, KiB units, FETCH_SIZE x2 on
+    # gfx950 as MI355X_MICROARCH.md prescribes), summarised into profiles/per_layer_latest.json.
+    traffic, traffic_src = None, None
+    pj = os.path.join(ROOT, "profiles", "per_layer_latest.json")
+    if os.path.isfile(pj) and B == B_PER_GPU and W == W_LINE:
+        with open(pj) as f:
+            rows = [r for r in json.load(f) if r["layer"] in DOMINANT and r.get("fetch_gb_x2") is not None]
+        if rows:
+            traffic = float(np.mean([(r["fetch_gb_x2"] + r["write_gb"]) * 1e9 for r in rows]))
+            traffic_src = "profiles/per_layer_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     if args.layers:
         for name, v in prof.items():
             print("%-24s %9.3f ms" % (name, float(np.mean(v))), file=sys.stderr)
+    if args.layer_file:
+        with open(args.layer_file, "w") as f:
+            f.write("\n".join(prof.keys()) + "\n")
     result = {
         "metric": "text-lines/sec (1x128x2000 synth) greedy decode",
         "value": round(lines_per_s, 3), "unit": "lines/s", "n_gpus": world, "steps": args.steps,
@@ -124,9 +139,11 @@ def main():
         "config": {"workload": "BASELINE configs[1]: B=%d x 1x128x%d uint8 lines per GPU, random-init hctr "
                                "(C=%d), forward + greedy CTC decode, labels to host" % (B, W, C),
                    "lines_per_gpu": B, "width": W, "classes": C, "parallelism": "batch-shard x%d" % world},
-        "roofline": {"bound": "mfma", "kernel": "conv_mfma 3x3 512->512 @H=16 (10 launches/step)",
+        "roofline": {"bound": "mfma", "kernel": "conv3x3_halo 3x3 512->512 @H=16 (10 launches/step)",
                      "achieved": round(dom_tflops, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(dom_tflops / PEAK_F16_TFLOPS, 4), "traffic": None,
+                     "frac": round(dom_tflops / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                     "traffic_unit": "bytes/launch (algorithmic: 2.36e9 in + 2.36e9 out + 4.7e6 weights)",
+                     "traffic_source": traffic_src,
                      "avg_launch_ms": round(dom_avg_ms, 4),
                      "flops_per_launch": FLOP_PER_COL_DOM * cols},
         "whole_forward": {"kernel_ms_per_step": round(kernel_ms, 3),

@@ -32,6 +32,7 @@ struct ConvArgs {
     int64_t M;              // linear mode: number of rows
     int64_t ldo;            // linear mode: output leading dimension (elements)
     int mtiles, ntiles;
+    int dbg;                // timing experiments only (HCTR_DBG): 1 = DMA from fixed hot addresses, 2 = no DMA in the loop
 };
 
 // tile configurations: (couts x pixels) per 256-thread block

@@ -4,6 +4,8 @@
 // tiling, layouts and fusion are this engine's own. Wavefront = 64 lanes throughout.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace hctr {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -11,156 +13,32 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const void __attribute__((address_space(1))) * gptr_t;
 typedef void __attribute__((address_space(3))) * lptr_t;
 
+// One 1-KiB LDS-DMA piece (global_load_lds_dwordx4: lane i -> LDS lds_dst + 16*i) issued from inline
+// asm. hipcc's waitcnt pass drains lgkmcnt(0) at every wait while it can see an LDS-DMA in flight
+// (measured: perfect counted waits once the DMA is hidden), so kernels that software-pipeline their
+// ds_reads issue the DMA this way and retire it themselves with `s_waitcnt vmcnt(0)` before the
+// barrier. M0 carries the LDS byte address and is restored (cdna guide section 5.7).
+__device__ __forceinline__ void glds16_asm(const char* gsrc, char* lds_dst) {
+    const uint32_t lds = (uint32_t)(uintptr_t)((lptr_t)lds_dst);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds)
+                 : "memory");
+}
+
 // -------------------------------------------------------------------------------------------
-// conv_mfma: 3x3 (pad 1) / 1x1 convolution + folded BatchNorm (+ReLU, +(2,1) max-pool,
-// +squeeze-excite partial sums) as an implicit GEMM on v_mfma_f32_16x16x32_f16.
-//
-// Reference ops fused here: nn.Conv2d(k,1,pad) -> BatchNorm2d(eval) -> ReLU -> max_pool2d((2,1))
-// (models/handwritten_ctr_model.py:116-150, 47-53) and the spatial sum that SELayer's
-// AdaptiveAvgPool2d needs (:27); in linear mode: self.linear (:175).
-//
-// GEMM view: D[cout][pixel] = sum_{tap,cin} Wt[tap][cout][cin] * X[pixel + tap][cin]
-//   MFMA A operand = weights (rows = couts), B operand = pixels (cols), so every lane ends up with
-//   16 consecutive couts of one pixel = one 32-byte NHWC store.
-// Block = WN x WM waves; each wave owns JT*16 couts x 64 pixels (JT x 4 MFMA tiles): 64 couts
-//   (64 fp32 acc regs) for the 64x256 and 128x128 block tiles, 128 couts for the 256x256 tile.
-//   conv mode: a wave's 64 pixels are a 4-row x 16-column patch; MFMA column c = image column,
-//   pixel repeat n = image row, so the (2,1) max-pool pairs repeats (0,1),(2,3) inside a lane.
-// K loop: taps x (Cin/64) steps; both operand tiles ([rows][64 cin] fp16 = 128-byte rows) are
-//   staged with global_load_lds_dwordx4 into a double-buffered LDS image. The zero padding of the
-//   convolution is stored in memory (1-pixel zero border), so a tap is only an address offset.
-// LDS image: linear per wave-instruction (8 rows x 128 B), 16-byte chunk index XOR (row & 7)
-//   applied on the global SOURCE address and again on the ds_read_b128 address (conflict-free for
-//   the 16x16x32 operand pattern; cdna guide rule 21).
+// Shared epilogue of the MFMA conv kernels: + folded-BN bias, optional SE partial sums, ReLU,
+// (2,1) max-pool, zeroing of columns >= W, fp16 NHWC store (or fp32 rows in linear mode).
+// lane (q, c): for cout block cb (64 couts) the lane owns couts q*16 + jj*4 + i (jj = j & 3), i.e.
+// 16 consecutive couts, of pixel column c and pixel repeat n.
 // -------------------------------------------------------------------------------------------
-template <int WN, int WM, int JT, int TAPS, bool LINEAR>
-__global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a) {
-    constexpr int NT = WN * WM * 64;
-    constexpr int WC = JT * 16;          // couts per wave (64 or 128)
+template <int WN, int WM, int JT, bool LINEAR>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT][4], char* smem, int tid, int lane,
+                                              int wn, int wm, int n0, int mt, int img, int th, int tw) {
+    constexpr int WC = JT * 16;
     constexpr int BN = WN * WC, BM = WM * 64;
-    constexpr int NIW = BN * 8 / NT;     // 16-byte chunks of the weight tile per thread
-    constexpr int NIX = BM * 8 / NT;     // ... of the pixel tile
-    constexpr int TILE_BYTES = (BN + BM) * 128;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wv / WM, wm = wv % WM;
-
-    // ---- block -> (m_tile, n_tile), XCD-aware: each XCD walks a contiguous run of the
-    //      (m-major, n-minor) order so the n-tiles of one pixel tile share that XCD's L2.
-    const int total = a.mtiles * a.ntiles;
-    int lin;
-    {
-        const int id = blockIdx.x, xcd = id & 7, s = id >> 3;
-        const int q = total >> 3, r = total & 7;
-        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + s;
-    }
-    const int nt = lin % a.ntiles;
-    const int mt = lin / a.ntiles;
-    const int n0 = nt * BN;
-
-    int img = 0, th = 0, tw = 0;
-    if (!LINEAR) {
-        tw = mt % a.tilesW;
-        const int t2 = mt / a.tilesW;
-        th = t2 % a.tilesH;
-        img = t2 / a.tilesH;
-    }
-    const int cin = a.Cin;
-
-    // ---- per-thread staging sources: uniform base (SGPRs) + 32-bit per-lane byte offset ----
-    const char* xbase;
-    if (LINEAR) xbase = (const char*)(a.x + (int64_t)mt * BM * cin);
-    else xbase = (const char*)(a.x + img * a.in_sb);
-    const char* wbase = (const char*)(a.w + (int64_t)n0 * cin);
-    uint32_t xoff[NIX], woff[NIW];
-#pragma unroll
-    for (int i = 0; i < NIX; ++i) {
-        const int g = (wv * NIX + i) * 64 + lane;
-        const int row = g >> 3, cp = (g & 7) ^ (row & 7);
-        if (LINEAR) {
-            int64_t rem = a.M - (int64_t)mt * BM;            // rows left in this tile (>= 1)
-            const int r = (int64_t)row < rem ? row : (int)rem - 1;
-            xoff[i] = (uint32_t)r * (uint32_t)cin * 2u + cp * 16;
-        } else {
-            const int h = th * (4 * WM) + (row >> 6) * 4 + ((row >> 4) & 3);
-            const int w = tw * kTileW + (row & 15);
-            xoff[i] = ((uint32_t)(h + 1) * (uint32_t)a.in_sh + (uint32_t)(w + 1) * (uint32_t)cin) * 2u + cp * 16;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NIW; ++i) {
-        const int g = (wv * NIW + i) * 64 + lane;
-        const int row = g >> 3, cp = (g & 7) ^ (row & 7);
-        woff[i] = (uint32_t)row * (uint32_t)cin * 2u + cp * 16;
-    }
-
-    const int kc_steps = cin / kBK;
-    const int nk = TAPS * kc_steps;
-
-    auto stage = [&](int k, int buf) {
-        int tap = 0, kc = k;
-        if (TAPS > 1) { tap = k / kc_steps; kc = k - tap * kc_steps; }
-        int64_t xo = (int64_t)kc * (kBK * 2);
-        if (TAPS > 1) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            xo += ((int64_t)dy * a.in_sh + (int64_t)dx * cin) * 2;
-        }
-        const int64_t wo = ((int64_t)tap * a.CoutPad * cin + (int64_t)kc * kBK) * 2;
-        const char* xs = xbase + xo;
-        const char* wsrc = wbase + wo;
-        char* wdst = smem + buf * TILE_BYTES + (wv * NIW) * 1024;
-        char* xdst = smem + buf * TILE_BYTES + BN * 128 + (wv * NIX) * 1024;
-#pragma unroll
-        for (int i = 0; i < NIW; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + woff[i]), (lptr_t)(wdst + i * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < NIX; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(xs + xoff[i]), (lptr_t)(xdst + i * 1024), 16, 0, 0);
-    };
-
-    f32x4 acc[JT][4];
-#pragma unroll
-    for (int j = 0; j < JT; ++j)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // per-lane fragment offsets inside a tile: row (lane&15), logical chunk ks*4 + (lane>>4)
     const int q = lane >> 4;
-    const int frow = lane & 15;
-    const int foff0 = frow * 128 + (((0 + q) ^ (lane & 7)) << 4);
-    const int foff1 = frow * 128 + (((4 + q) ^ (lane & 7)) << 4);
-
-    stage(0, 0);
-    for (int k = 0; k < nk; ++k) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (k + 1 < nk) stage(k + 1, (k + 1) & 1);
-        const char* wt = smem + (k & 1) * TILE_BYTES + (wn * WC) * 128;
-        const char* xt = smem + (k & 1) * TILE_BYTES + BN * 128 + (wm * 64) * 128;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int fo = ks ? foff1 : foff0;
-            f16x8 af[JT], bf[4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) bf[n] = *(const f16x8*)(xt + n * 2048 + fo);
-#pragma unroll
-            for (int j = 0; j < JT; ++j) af[j] = *(const f16x8*)(wt + j * 2048 + fo);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int j = 0; j < JT; ++j)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], bf[n], acc[j][n], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        }
-    }
-
-    // ---- epilogue ---------------------------------------------------------------------------
-    // lane (q, c): for cout block cb (64 couts) the lane owns couts q*16 + jj*4 + i (jj = j & 3),
-    // i.e. 16 consecutive couts, of pixel column c and pixel repeat n.
     const int c = lane & 15;
     const int cw0 = n0 + wn * WC + q * 16;      // + cb*64 + jj*4 + i
 
@@ -193,6 +71,7 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
     if (a.se_part != nullptr) {
         // per-(image, channel) sums over this block's valid pixels, fixed reduction order
         // (deterministic: lane tree -> LDS -> one partial row per block; reduced later by se_fc).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // PIPE: last (redundant) DMA has landed
         __syncthreads();                       // main-loop LDS no longer needed
         float* red = (float*)smem;             // [WM][BN]
 #pragma unroll
@@ -260,6 +139,405 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
     }
 }
 
+// -------------------------------------------------------------------------------------------
+// conv_mfma: 3x3 (pad 1) / 1x1 convolution + folded BatchNorm (+ReLU, +(2,1) max-pool,
+// +squeeze-excite partial sums) as an implicit GEMM on v_mfma_f32_16x16x32_f16.
+//
+// Reference ops fused here: nn.Conv2d(k,1,pad) -> BatchNorm2d(eval) -> ReLU -> max_pool2d((2,1))
+// (models/handwritten_ctr_model.py:116-150, 47-53) and the spatial sum that SELayer's
+// AdaptiveAvgPool2d needs (:27); in linear mode: self.linear (:175).
+//
+// GEMM view: D[cout][pixel] = sum_{tap,cin} Wt[tap][cout][cin] * X[pixel + tap][cin]
+//   MFMA A operand = weights (rows = couts), B operand = pixels (cols), so every lane ends up with
+//   16 consecutive couts of one pixel = one 32-byte NHWC store.
+// Block = WN x WM waves; each wave owns JT*16 couts x 64 pixels (JT x 4 MFMA tiles): 64 couts
+//   (64 fp32 acc regs) for the 64x256 and 128x128 block tiles, 128 couts for the 256x256 tile.
+//   conv mode: a wave's 64 pixels are a 4-row x 16-column patch; MFMA column c = image column,
+//   pixel repeat n = image row, so the (2,1) max-pool pairs repeats (0,1),(2,3) inside a lane.
+// K loop: taps x (Cin/64) steps; both operand tiles ([rows][64 cin] fp16 = 128-byte rows) are
+//   staged with global_load_lds_dwordx4 into a double-buffered LDS image. The zero padding of the
+//   convolution is stored in memory (1-pixel zero border), so a tap is only an address offset.
+// LDS image: linear per wave-instruction (8 rows x 128 B), 16-byte chunk index XOR (row & 7)
+//   applied on the global SOURCE address and again on the ds_read_b128 address (conflict-free for
+//   the 16x16x32 operand pattern; cdna guide rule 21).
+// -------------------------------------------------------------------------------------------
+template <int WN, int WM, int JT, int TAPS, bool LINEAR, bool PIPE>
+__global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a) {
+    constexpr int NT = WN * WM * 64;
+    constexpr int WC = JT * 16;          // couts per wave (64 or 128)
+    constexpr int BN = WN * WC, BM = WM * 64;
+    constexpr int NIW = BN * 8 / NT;     // 16-byte chunks of the weight tile per thread
+    constexpr int NIX = BM * 8 / NT;     // ... of the pixel tile
+    constexpr int TILE_BYTES = (BN + BM) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv / WM, wm = wv % WM;
+
+    // ---- block -> (m_tile, n_tile), XCD-aware: each XCD walks a contiguous run of the
+    //      (m-major, n-minor) order so the n-tiles of one pixel tile share that XCD's L2.
+    const int total = a.mtiles * a.ntiles;
+    int lin;
+    {
+        const int id = blockIdx.x, xcd = id & 7, s = id >> 3;
+        const int q = total >> 3, r = total & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + s;
+    }
+    const int nt = lin % a.ntiles;
+    const int mt = lin / a.ntiles;
+    const int n0 = nt * BN;
+
+    int img = 0, th = 0, tw = 0;
+    if (!LINEAR) {
+        tw = mt % a.tilesW;
+        const int t2 = mt / a.tilesW;
+        th = t2 % a.tilesH;
+        img = t2 / a.tilesH;
+    }
+    const int cin = a.Cin;
+
+    // ---- per-thread staging sources: uniform base (SGPRs) + 32-bit per-lane byte offset ----
+    const char* xbase;
+    if (LINEAR) xbase = (const char*)(a.x + (int64_t)mt * BM * cin);
+    else xbase = (const char*)(a.x + img * a.in_sb);
+    const char* wbase = (const char*)(a.w + (int64_t)n0 * cin);
+    uint32_t xoff[NIX], woff[NIW];
+#pragma unroll
+    for (int i = 0; i < NIX; ++i) {
+        const int g = (wv * NIX + i) * 64 + lane;
+        const int row = g >> 3, cp = (g & 7) ^ (row & 7);
+        if (LINEAR) {
+            int64_t rem = a.M - (int64_t)mt * BM;            // rows left in this tile (>= 1)
+            const int r = (int64_t)row < rem ? row : (int)rem - 1;
+            xoff[i] = (uint32_t)r * (uint32_t)cin * 2u + cp * 16;
+        } else {
+            const int h = th * (4 * WM) + (row >> 6) * 4 + ((row >> 4) & 3);
+            const int w = tw * kTileW + (row & 15);
+            xoff[i] = ((uint32_t)(h + 1) * (uint32_t)a.in_sh + (uint32_t)(w + 1) * (uint32_t)cin) * 2u + cp * 16;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+        const int g = (wv * NIW + i) * 64 + lane;
+        const int row = g >> 3, cp = (g & 7) ^ (row & 7);
+        woff[i] = (uint32_t)row * (uint32_t)cin * 2u + cp * 16;
+    }
+
+    const int kc_steps = cin / kBK;
+    const int nk = TAPS * kc_steps;
+
+    // uniform source offsets of K step k. Order: 64-channel chunk outermost, the 9 taps innermost, so
+    // a block re-reads the same 18x18-pixel x 128-byte halo (41 KB) nine times in a row out of L1/L2.
+    // (Tap-major order swept all Cin per tap: reuse distance 256 KB x 32 blocks per XCD >> 4 MB L2,
+    // measured 17.4 GB FETCH_SIZE per 512->512@16 launch against 2.4 GB of input.)
+    auto step_offsets = [&](int k, int64_t& wo, int64_t& xo) {
+        int tap = 0, kc = k;
+        if (TAPS > 1) { kc = k / TAPS; tap = k - kc * TAPS; }
+        xo = (int64_t)kc * (kBK * 2);
+        if (TAPS > 1) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            xo += ((int64_t)dy * a.in_sh + (int64_t)dx * cin) * 2;
+        }
+        wo = ((int64_t)tap * a.CoutPad * cin + (int64_t)kc * kBK) * 2;
+    };
+    // one 1-KiB LDS-DMA piece (idx < NIW: weight tile, else pixel tile) into buffer buf
+    auto stage_piece = [&](const char* wsrc, const char* xsrc, int buf, int idx) {
+        if (idx < NIW) {
+            char* wdst = smem + buf * TILE_BYTES + (wv * NIW) * 1024;
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + woff[idx]), (lptr_t)(wdst + idx * 1024), 16, 0, 0);
+        } else {
+            char* xdst = smem + buf * TILE_BYTES + BN * 128 + (wv * NIX) * 1024;
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc + xoff[idx - NIW]), (lptr_t)(xdst + (idx - NIW) * 1024), 16, 0, 0);
+        }
+    };
+    auto stage = [&](int k, int buf) {
+        int64_t wo, xo;
+        step_offsets(k, wo, xo);
+#pragma unroll
+        for (int i = 0; i < NIW + NIX; ++i) stage_piece(wbase + wo, xbase + xo, buf, i);
+    };
+
+    f32x4 acc[JT][4];
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane fragment offsets inside a tile: row (lane&15), logical chunk ks*4 + (lane>>4)
+    const int q = lane >> 4;
+    const int frow = lane & 15;
+    const int foff0 = frow * 128 + (((0 + q) ^ (lane & 7)) << 4);
+    const int foff1 = frow * 128 + (((4 + q) ^ (lane & 7)) << 4);
+
+    stage(0, 0);
+    if (!PIPE) {
+        for (int k = 0; k < nk; ++k) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (k + 1 < nk) stage(k + 1, (k + 1) & 1);
+            const char* wt = smem + (k & 1) * TILE_BYTES + (wn * WC) * 128;
+            const char* xt = smem + (k & 1) * TILE_BYTES + BN * 128 + (wm * 64) * 128;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int fo = ks ? foff1 : foff0;
+                f16x8 af[JT], bf[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bf[n] = *(const f16x8*)(xt + n * 2048 + fo);
+#pragma unroll
+                for (int j = 0; j < JT; ++j) af[j] = *(const f16x8*)(wt + j * 2048 + fo);
+                __builtin_amdgcn_s_setprio(1);     // keeps the MFMA cluster together (measured +4 %)
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], bf[n], acc[j][n], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+    } else {
+        // Finely interleaved K step: 2*JT groups of {prefetch the next A fragment, one LDS-DMA piece of
+        // the next K step every other group, 4 MFMAs}. The two waves that share a SIMD then mix memory
+        // issue and matrix work instead of bursting both at the barrier. Measured on MI355X (round 1,
+        // config 2): 8.25 ms vs 7.75-8.05 ms per dominant launch for the burst form, so it is OFF by
+        // default (HCTR_PIPE=1 enables it for A/B runs).
+        constexpr int NG = 2 * JT;
+        constexpr int NP = NIW + NIX;
+        for (int k = 0; k < nk; ++k) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // next step's DMA is unconditional (branch-free loop): on the last step it re-stages that
+            // step into the idle buffer, which nobody reads (drained before the epilogue reuses LDS).
+            const int kn = k + 1 < nk ? k + 1 : k;
+            int64_t wo_n, xo_n;
+            step_offsets(kn, wo_n, xo_n);
+            const char* wsrc_n = wbase + wo_n;
+            const char* xsrc_n = xbase + xo_n;
+            const int buf_n = (k + 1) & 1;
+            const char* wt = smem + (k & 1) * TILE_BYTES + (wn * WC) * 128;
+            const char* xt = smem + (k & 1) * TILE_BYTES + BN * 128 + (wm * 64) * 128;
+            f16x8 bfr[2][4], afr[2];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bfr[0][n] = *(const f16x8*)(xt + n * 2048 + foff0);
+            afr[0] = *(const f16x8*)(wt + foff0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int ks = g / JT, j = g % JT;
+                if (g + 1 < NG) {
+                    const int ks1 = (g + 1) / JT, j1 = (g + 1) % JT;
+                    afr[(g + 1) & 1] = *(const f16x8*)(wt + j1 * 2048 + (ks1 ? foff1 : foff0));
+                }
+                if (g == JT / 2) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) bfr[1][n] = *(const f16x8*)(xt + n * 2048 + foff1);
+                }
+                if ((g * NP) / NG != ((g + 1) * NP) / NG)      // NP pieces spread over NG groups
+                    stage_piece(wsrc_n, xsrc_n, buf_n, (g * NP) / NG);
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[g & 1], bfr[ks][n], acc[j][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    conv_epilogue<WN, WM, JT, LINEAR>(a, acc, smem, tid, lane, wn, wm, n0, mt, img, th, tw);
+}
+
+// -------------------------------------------------------------------------------------------
+// conv3x3_halo: the 3x3 layers on the 256-cout x (16x16-pixel) tile with the pixel operand staged
+// ONCE per 64-channel chunk. The generic kernel re-stages a shifted 16x16 window for each of the
+// 9 taps (8 LDS-DMA pieces per wave per K step); on MI355X the burst of DMA issue after every
+// barrier is what idles the matrix pipe (SQ counters: MFMA busy 56 %, no LDS conflicts, fabric
+// traffic irrelevant). Here a block keeps an 18x18-pixel halo x 64 channels (rows of 128 B, row
+// stride 20 pixels so the swizzle key stays cheap) in LDS and reads the tap-shifted B fragments from
+// it, so only the 32 KB weight tile streams per K step: 4 + 6/9 pieces per wave per step instead of 8.
+// LDS: 2 x 32 KB weights (double-buffered per K step) + 2 x 45 KB halo (double-buffered per chunk).
+// -------------------------------------------------------------------------------------------
+constexpr int kHaloCols = 20;                            // row stride in pixels (18 used)
+constexpr int kHaloRows = 18;
+constexpr int kHaloBytes = kHaloRows * kHaloCols * 128;  // 46080
+constexpr int kHaloPieces = kHaloRows * kHaloCols / 8;   // 45 one-KiB DMA pieces
+constexpr int kHaloLds = 2 * 32768 + 2 * kHaloBytes;     // 157696
+
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvArgs a) {
+    constexpr int WN = 2, WM = 4, JT = 8, BN = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv / WM, wm = wv % WM;
+
+    const int total = a.mtiles * a.ntiles;
+    int lin;
+    {
+        const int id = blockIdx.x, xcd = id & 7, s = id >> 3;
+        const int q = total >> 3, r = total & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + s;
+    }
+    const int nt = lin % a.ntiles;
+    const int mt = lin / a.ntiles;
+    const int n0 = nt * BN;
+    const int tw = mt % a.tilesW;
+    const int t2 = mt / a.tilesW;
+    const int th = t2 % a.tilesH;
+    const int img = t2 / a.tilesH;
+    const int cin = a.Cin;
+    const int nkc = cin / kBK;
+
+    // ---- DMA sources ------------------------------------------------------------------------
+    // halo origin = padded pixel (th*16, tw*16) = output pixel (th*16 - 1, tw*16 - 1)
+    const char* xbase = (const char*)(a.x + img * a.in_sb + (int64_t)(th * 16) * a.in_sh + (int64_t)(tw * 16) * cin);
+    const char* wbase = (const char*)(a.w + (int64_t)n0 * cin);
+    uint32_t woff[4], hoff[6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = (wv * 4 + i) * 64 + lane;
+        const int row = g >> 3, cp = (g & 7) ^ (row & 7);
+        woff[i] = (uint32_t)row * (uint32_t)cin * 2u + cp * 16;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int g = (wv + 8 * r) * 64 + lane;            // piece wv + 8r
+        const int row = g >> 3, cp = (g & 7) ^ (row & 7);
+        int hy = row / kHaloCols, hx = row - hy * kHaloCols;
+        if (hx > 17) hx = 17;                               // pad columns: any valid address
+        if (hy > 17) hy = 17;                               // pieces >= 45 are never issued
+        hoff[r] = ((uint32_t)hy * (uint32_t)a.in_sh + (uint32_t)hx * (uint32_t)cin) * 2u + cp * 16;
+    }
+    const int q = lane >> 4, c = lane & 15;
+    const int aoff0 = c * 128 + (((0 + q) ^ (lane & 7)) << 4);
+    const int aoff1 = c * 128 + (((4 + q) ^ (lane & 7)) << 4);
+
+    auto stage_weights = [&](int kc, int tap, int buf) {
+        const char* src = wbase + ((int64_t)tap * a.CoutPad * cin + (int64_t)kc * kBK) * 2;
+        char* dst = smem + buf * 32768 + (wv * 4) * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            glds16_asm(src + woff[i], dst + i * 1024);
+    };
+    auto stage_halo_piece = [&](int kc, int buf, int r, uint32_t off) {
+        if (wv + 8 * r < kHaloPieces) {                     // wave-uniform
+            const char* src = xbase + (int64_t)kc * (kBK * 2);
+            char* dst = smem + 65536 + buf * kHaloBytes + (wv + 8 * r) * 1024;
+            glds16_asm(src + off, dst);
+        }
+    };
+
+    f32x4 acc[JT][4];
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int r = 0; r < 6; ++r) stage_halo_piece(0, 0, r, hoff[r]);
+    stage_weights(0, 0, 0);
+
+    for (int kc = 0; kc < nkc; ++kc) {
+        const bool next_chunk = kc + 1 < nkc;
+        const int hbuf = 65536 + (kc & 1) * kHaloBytes + (wm * 4) * (kHaloCols * 128);
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int k = kc * 9 + tap;
+            // Retire the previous step's DMA. Steps 0..4 of a chunk issue (after the 4 weight pieces) one
+            // piece of the NEXT chunk's halo from every wave; that piece is cold (HBM) and not needed for
+            // several steps, so it may stay in flight across this barrier: vmcnt(1) retires everything
+            // older (vmcnt counts in issue order). All other steps drain completely.
+            if (tap >= 1 && tap <= 5 && next_chunk) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // next K step's weights (clamped on the very last step: re-stages into the idle buffer)
+            {
+                int kc1 = kc, tap1 = tap + 1;
+                if (tap1 == 9) { tap1 = 0; kc1 = next_chunk ? kc + 1 : kc; }
+                if (a.dbg == 1) { kc1 = 0; tap1 = 0; }
+                if (a.dbg != 2) stage_weights(kc1, tap1, (k + 1) & 1);
+            }
+            // next chunk's halo: piece (wv + 8*tap) on steps 0..5 (branch-free select of the offset)
+            {
+                uint32_t ho = hoff[0];
+                ho = tap == 1 ? hoff[1] : ho;
+                ho = tap == 2 ? hoff[2] : ho;
+                ho = tap == 3 ? hoff[3] : ho;
+                ho = tap == 4 ? hoff[4] : ho;
+                ho = tap == 5 ? hoff[5] : ho;
+                if (next_chunk && tap < 6 && wv + 8 * tap < kHaloPieces && a.dbg != 2) {   // tap 5: waves 0..4
+                    const char* src = xbase + (int64_t)(a.dbg == 1 ? 0 : kc + 1) * (kBK * 2);
+                    char* dst = smem + 65536 + ((kc + 1) & 1) * kHaloBytes + (wv + 8 * tap) * 1024;
+                    glds16_asm(src + ho, dst);
+                }
+            }
+            // B fragments: halo pixel row index hr = (wm*4 + n + 1 + dy)*20 + (c + 1 + dx); swizzle key
+            // hr & 7 = ((c+1+dx) & 7) ^ 4*((n+1+dy) & 1)  (20 = 4 mod 8, +4 mod 8 = ^4). With the chunk
+            // index ks*4 + q, the four (ks, n parity) cases need only two per-lane offsets, v0 and v0^64.
+            const int tdy = tap / 3, dx = tap - tdy * 3 - 1;        // tdy = dy + 1
+            const int u = c + 1 + dx;
+            const int v0 = u * 128 + (((q ^ (u & 7) ^ ((tdy & 1) << 2)) & 7) << 4);
+            const char* hb = smem + hbuf + tdy * (kHaloCols * 128);
+            const char* be = hb + v0;           // ks=0 & n even, ks=1 & n odd
+            const char* bo = hb + (v0 ^ 64);    // ks=0 & n odd,  ks=1 & n even
+            const char* wt = smem + (k & 1) * 32768 + (wn * 128) * 128;
+            // Rolling fragment pipeline: 8 groups of 8 MFMAs (2 A fragments x 4 B fragments). A pairs
+            // are read two groups (16 MFMAs = 256 cycles) ahead into a 3-slot ring, the next ks's B
+            // fragments during groups 1-2, so only the first 8 reads after the barrier are exposed.
+            f16x8 ar[3][2], bq[2][4];
+            auto read_a = [&](int g, f16x8 (&dst)[2]) {
+                const int ks = g >> 2, jp = g & 3;
+                const char* base = wt + (ks ? aoff1 : aoff0);
+                dst[0] = *(const f16x8*)(base + (2 * jp) * 2048);
+                dst[1] = *(const f16x8*)(base + (2 * jp + 1) * 2048);
+            };
+            auto read_b = [&](int ks, f16x8 (&dst)[4]) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    dst[n] = *(const f16x8*)((((n & 1) ^ ks) ? bo : be) + n * (kHaloCols * 128));
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            read_b(0, bq[0]);
+            read_a(0, ar[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(1, ar[1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int ks = g >> 2, jp = g & 3;
+                if (g + 2 < 8) read_a(g + 2, ar[(g + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g == 1) { read_b(1, bq[1]); __builtin_amdgcn_sched_barrier(0); }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[2 * jp + jj][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[g % 3][jj], bq[ks][n],
+                                                                                    acc[2 * jp + jj][n], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last (redundant) DMA has landed
+    conv_epilogue<WN, WM, JT, false>(a, acc, smem, tid, lane, wn, wm, n0, mt, img, th, tw);
+}
+
+static hipError_t launch_conv_halo(const ConvArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           kHaloLds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    static const int dbg = [] { const char* e = getenv("HCTR_DBG"); return e ? atoi(e) : 0; }();
+    ConvArgs b = a;
+    b.dbg = dbg;
+    hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(a.mtiles * a.ntiles), dim3(512), kHaloLds, s, b);
+    return hipGetLastError();
+}
+
 size_t conv_lds_bytes(ConvTile tile) {
     switch (tile) {
         case TILE_64x256: return 2 * (64 + 256) * 128;
@@ -268,9 +546,9 @@ size_t conv_lds_bytes(ConvTile tile) {
     }
 }
 
-template <int WN, int WM, int JT, int TAPS, bool LINEAR>
+template <int WN, int WM, int JT, int TAPS, bool LINEAR, bool PIPE>
 static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
-    auto kern = conv_mfma_kernel<WN, WM, JT, TAPS, LINEAR>;
+    auto kern = conv_mfma_kernel<WN, WM, JT, TAPS, LINEAR, PIPE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -284,17 +562,26 @@ static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
 
 hipError_t launch_conv(const ConvArgs& a, ConvTile tile, int taps, bool linear_f32, hipStream_t s) {
     const size_t lds = conv_lds_bytes(tile);
+    static const bool halo = [] { const char* e = getenv("HCTR_HALO"); return e ? atoi(e) != 0 : true; }();
+    static const bool pipe = [] { const char* e = getenv("HCTR_PIPE"); return e ? atoi(e) != 0 : false; }();
     if (linear_f32) {
-        return tile == TILE_256x256 ? launch_conv_t<2, 4, 8, 1, true>(a, lds, s)
-                                    : launch_conv_t<2, 2, 4, 1, true>(a, lds, s);
+        if (tile == TILE_256x256)
+            return pipe ? launch_conv_t<2, 4, 8, 1, true, true>(a, lds, s) : launch_conv_t<2, 4, 8, 1, true, false>(a, lds, s);
+        return launch_conv_t<2, 2, 4, 1, true, false>(a, lds, s);
     }
     switch (tile) {
         case TILE_64x256:
-            return taps == 9 ? launch_conv_t<1, 4, 4, 9, false>(a, lds, s) : launch_conv_t<1, 4, 4, 1, false>(a, lds, s);
+            return taps == 9 ? launch_conv_t<1, 4, 4, 9, false, false>(a, lds, s)
+                             : launch_conv_t<1, 4, 4, 1, false, false>(a, lds, s);
         case TILE_256x256:
-            return taps == 9 ? launch_conv_t<2, 4, 8, 9, false>(a, lds, s) : launch_conv_t<2, 4, 8, 1, false>(a, lds, s);
+            if (taps == 9 && halo) return launch_conv_halo(a, s);
+            if (taps == 9)
+                return pipe ? launch_conv_t<2, 4, 8, 9, false, true>(a, lds, s)
+                            : launch_conv_t<2, 4, 8, 9, false, false>(a, lds, s);
+            return launch_conv_t<2, 4, 8, 1, false, false>(a, lds, s);
         default:
-            return taps == 9 ? launch_conv_t<2, 2, 4, 9, false>(a, lds, s) : launch_conv_t<2, 2, 4, 1, false>(a, lds, s);
+            return taps == 9 ? launch_conv_t<2, 2, 4, 9, false, false>(a, lds, s)
+                             : launch_conv_t<2, 2, 4, 1, false, false>(a, lds, s);
     }
 }
 

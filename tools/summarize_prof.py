@@ -50,5 +50,48 @@ def main(d):
                                                         100.0 * sum(v) / total, fs, wsz))
 
 
+def per_layer(d):
+    """Label the launches of the LAST full step with the engine's layer names (launch order written by
+    bench.py --layer-file) and attach each launch's PMC bytes (same position in the PMC runs)."""
+    lf = os.path.join(d, "layers.txt")
+    if not os.path.isfile(lf):
+        return
+    names = [l.strip() for l in open(lf) if l.strip()]
+
+    def engine_rows(path, key_start, key_end):
+        rows = [r for r in csv.DictReader(open(path)) if "hctr" in r["Kernel_Name"]]
+        rows.sort(key=lambda r: int(r[key_start]))
+        return rows
+
+    trace = engine_rows(glob.glob(os.path.join(d, "stats", "*", "*_kernel_trace.csv"))[0], "Start_Timestamp", None)
+    n = len(names)
+    last = trace[-n:]
+    if len(last) != n or "stem" not in last[0]["Kernel_Name"]:
+        print("\n(per-layer table skipped: launch order does not line up)")
+        return
+    pm = {}
+    for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        files = glob.glob(os.path.join(d, "pmc_" + kind, "*", "*_counter_collection.csv"))
+        if files:
+            rows = [r for r in csv.DictReader(open(files[0])) if "hctr" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+            rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+            pm[kind] = rows[-n:] if len(rows) >= n else None
+    print("\n## Last step, per launch\n")
+    print("| layer | kernel | ms | FETCH_SIZE GB (raw / x2) | WRITE_SIZE GB |")
+    print("|---|---|---|---|---|")
+    out = []
+    for i, (nm, r) in enumerate(zip(names, last)):
+        ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        f = float(pm["fetch"][i]["Counter_Value"]) * 1024 / 1e9 if pm.get("fetch") else None
+        w = float(pm["write"][i]["Counter_Value"]) * 1024 / 1e9 if pm.get("write") else None
+        print("| %s | %s | %.3f | %s | %s |" % (nm, short(r["Kernel_Name"]), ms,
+              "%.3f / %.3f" % (f, 2 * f) if f is not None else "-", "%.3f" % w if w is not None else "-"))
+        out.append({"layer": nm, "ms": ms, "fetch_gb_x2": 2 * f if f is not None else None, "write_gb": w})
+    import json
+    with open(os.path.join(d, "per_layer.json"), "w") as fjs:
+        json.dump(out, fjs, indent=1)
+
+
 if __name__ == "__main__":
     main(sys.argv[1])
+    per_layer(sys.argv[1])
