@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--cpu-lines", type=int, default=2)
     ap.add_argument("--layers", action="store_true", help="print the per-layer device-time table to stderr")
     ap.add_argument("--layer-file", default="", help="write the per-step launch order (layer names) to this file")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"],
+                    help="c2 (default, the driver's line): B=64 x W=2000 greedy; c3: B=512 mixed widths "
+                         "{800,1600,2400,3200} bucketed; c5: B=256 x W=2000 beam search 10/10 (extra modes, 1 GPU)")
     args = ap.parse_args()
 
     import torch
@@ -69,6 +72,8 @@ def main():
     model = hctr_amd.hctr_model(C).cuda(local)
     model.load_state_dict(sd)
     model.eval()
+    if args.config != "c2":
+        return extra_config(args, hctr_amd, model, sd, dev)
     # this rank's contiguous shard of the global synthetic batch (seed, global line index)
     imgs_host = synth.make_line_images(B, W, SEED, line_offset=rank * B)
     imgs = torch.from_numpy(imgs_host).to(dev)              # resident in HBM before timing
@@ -170,6 +175,68 @@ def main():
     print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def extra_config(args, hctr_amd, model, sd, dev):
+    """BASELINE configs 3 and 5 on one GPU (not the driver's line; results recorded in DESIGN.md)."""
+    import torch
+    synth = hctr_amd.synth
+    C = synth.DEFAULT_VOCAB + 2
+    codec = hctr_amd.ctc_codec(synth.characters()).attach(model)
+    if args.config == "c3":
+        buckets = []
+        for bi, w in enumerate((800, 1600, 2400, 3200)):
+            host = synth.make_line_images(128, w, 3, line_offset=bi * 128)
+            buckets.append((w, host, torch.from_numpy(host).to(dev)))
+        torch.cuda.synchronize(dev)
+
+        def step():
+            return [model.greedy(t) for _, _, t in buckets]
+        n_lines, cols = 512, sum(128 * w for w, _, _ in buckets)
+        name = "BASELINE configs[2]: B=512 mixed widths {800,1600,2400,3200}, 4 equal-width buckets of 128, greedy"
+    else:
+        host = synth.make_line_images(256, W_LINE, 5)
+        dev_imgs = torch.from_numpy(host).to(dev)
+        codec.use_beam_search, codec.use_tfm_pred, codec.skip_search = True, False, False
+        codec.beam_size = codec.search_depth = 10
+        codec.lm_panelty, codec.len_bonus = 0.8, 4.8          # test.py:74-79 defaults
+        codec.ngram = hctr_amd.ToyBigramLM()
+        t_front = [0.0]
+
+        def step():
+            t0 = time.perf_counter()
+            fe = model.beam_frontend(dev_imgs, k=10)
+            t_front[0] += time.perf_counter() - t0
+            return codec.decode_frontend(fe)
+        n_lines, cols = 256, 256 * W_LINE
+        name = ("BASELINE configs[4]: B=256 x 1x128x2000, cbs_full beam 10 / depth 10, toy-bigram LM, "
+                "device log-softmax+top-k, C++ host prefix search on %d threads" % len(os.sched_getaffinity(0)))
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    res = {"metric": "text-lines/sec", "value": round(n_lines * args.steps / dt, 3), "unit": "lines/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "higher_is_better": True, "dtype": "f16 (f32 accumulate)", "data": "synthetic",
+           "config": {"workload": name, "columns_per_step": cols},
+           "columns_per_s": round(cols * args.steps / dt, 1)}
+    if args.config == "c5":
+        from oracle import ctc_ref, hctr_ref
+        res["frontend_ms_per_step"] = round(t_front[0] / (args.steps + args.warmup) * 1e3, 2)
+        # parity: the oracle codec (CPU) on the ENGINE's logits for 2 lines must give the same strings
+        logits = model(host[:2])
+        oc = ctc_ref.CtcCodecRef(synth.characters())
+        oc.use_beam_search, oc.use_tfm_pred = True, False
+        oc.lm_panelty, oc.len_bonus, oc.ngram = 0.8, 4.8, ctc_ref.ToyBigramLM()
+        t0 = time.perf_counter()
+        want = oc.decode(logits)
+        res["cpu_codec_lines_per_s"] = round(2 / (time.perf_counter() - t0), 4)
+        res["beam_strings_equal_oracle_on_engine_logits"] = bool(want == out[:2])
+    print(json.dumps(res))
 
 
 if __name__ == "__main__":

@@ -92,7 +92,9 @@ struct hctr_ctx {
     ConvW stage_conv[4];
     ConvW head;
     std::vector<void*> wallocs;
-    Workspace ws;
+    Workspace ws;                       // the active workspace (a copy of one cache entry's pointers)
+    std::vector<Workspace> ws_cache;    // workspaces by (B, W), least recently used last
+    size_t ws_budget = (size_t)200 << 30;
     int64_t max_cols = kDefaultMaxCols;
     bool big_tiles = true;
     // profiling
@@ -292,37 +294,64 @@ int build_head(hctr_ctx* c) {
 inline int64_t act_elems(int B, int H, int Wa, int C) { return (int64_t)B * (H + 2) * Wa * C; }
 
 int ensure_workspace(hctr_ctx* c, int B, int W) {
-    Workspace& ws = c->ws;
-    if (ws.B == B && ws.W == W) return HCTR_OK;
+    if (c->ws.B == B && c->ws.W == W) return HCTR_OK;
+    // look in the cache (bucketed workloads alternate between a few (B, W) shapes; each workspace is
+    // tens of GB and must be zero-filled once so the stored conv borders are valid)
+    for (size_t i = 0; i < c->ws_cache.size(); ++i)
+        if (c->ws_cache[i].B == B && c->ws_cache[i].W == W) {
+            Workspace w = c->ws_cache[i];
+            c->ws_cache.erase(c->ws_cache.begin() + i);
+            c->ws_cache.insert(c->ws_cache.begin(), w);
+            c->ws = w;
+            return HCTR_OK;
+        }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    free_pool(ws.allocs);
-    ws = Workspace();
+    Workspace ws;
     ws.B = B; ws.W = W;
     const int tilesW = (W + kTileW - 1) / kTileW;
     const int Wa = tilesW * kTileW + 2;
     ws.Wa = Wa;
     const int64_t cols = (int64_t)B * W;
-    TRY(dev_alloc(c, ws.allocs, (char**)&ws.img, (size_t)cols * kImgH * 4, false, &ws.bytes));
-    TRY(dev_alloc(c, ws.allocs, &ws.widths, (size_t)B, false, &ws.bytes));
-    TRY(dev_alloc(c, ws.allocs, &ws.s0, (size_t)act_elems(B, 128, Wa, 64), true, &ws.bytes));
+    // estimate, then evict least-recently-used workspaces until the new one fits the budget
+    const size_t need = (size_t)cols * 300000;
+    while (!c->ws_cache.empty()) {
+        size_t used = 0;
+        for (auto& w : c->ws_cache) used += w.bytes;
+        if (used + need <= c->ws_budget) break;
+        free_pool(c->ws_cache.back().allocs);
+        c->ws_cache.pop_back();
+    }
+    c->ws = Workspace();
+    int rc = HCTR_OK;
+    auto A = [&](auto** out, size_t count, bool zero) {
+        if (rc == HCTR_OK) rc = dev_alloc(c, ws.allocs, out, count, zero, &ws.bytes);
+    };
+    A((char**)&ws.img, (size_t)cols * kImgH * 4, false);
+    A(&ws.widths, (size_t)B, false);
+    A(&ws.s0, (size_t)act_elems(B, 128, Wa, 64), true);
     int cin = 64;
     size_t se_max = 0;
     for (int s = 1; s <= 4; ++s) {
         const int H = kStageH[s], planes = kStagePlanes[s - 1];
-        TRY(dev_alloc(c, ws.allocs, &ws.x[s], (size_t)act_elems(B, H, Wa, cin), true, &ws.bytes));
+        A(&ws.x[s], (size_t)act_elems(B, H, Wa, cin), true);
         const int nbuf = (s == 4) ? 2 : 3;
-        for (int i = 0; i < nbuf; ++i)
-            TRY(dev_alloc(c, ws.allocs, &ws.p[s][i], (size_t)act_elems(B, H, Wa, planes), true, &ws.bytes));
+        for (int i = 0; i < nbuf; ++i) A(&ws.p[s][i], (size_t)act_elems(B, H, Wa, planes), true);
         se_max = std::max(se_max, (size_t)B * (H / 8) * tilesW * planes);
         cin = planes;
     }
-    TRY(dev_alloc(c, ws.allocs, &ws.headin, (size_t)cols * kFeat, false, &ws.bytes));
-    TRY(dev_alloc(c, ws.allocs, &ws.logits, (size_t)cols * c->cpad, false, &ws.bytes));
-    TRY(dev_alloc(c, ws.allocs, &ws.se_part, se_max, false, &ws.bytes));
-    TRY(dev_alloc(c, ws.allocs, &ws.se_scale, (size_t)B * 512, false, &ws.bytes));
-    TRY(dev_alloc(c, ws.allocs, &ws.colidx, (size_t)cols, false, &ws.bytes));
-    TRY(dev_alloc(c, ws.allocs, &ws.labels, (size_t)cols, false, &ws.bytes));
-    TRY(dev_alloc(c, ws.allocs, &ws.lengths, (size_t)B, false, &ws.bytes));
+    A(&ws.headin, (size_t)cols * kFeat, false);
+    A(&ws.logits, (size_t)cols * c->cpad, false);
+    A(&ws.se_part, se_max, false);
+    A(&ws.se_scale, (size_t)B * 512, false);
+    A(&ws.colidx, (size_t)cols, false);
+    A(&ws.labels, (size_t)cols, false);
+    A(&ws.lengths, (size_t)B, false);
+    if (rc != HCTR_OK) {
+        free_pool(ws.allocs);
+        return rc;
+    }
+    c->ws_cache.insert(c->ws_cache.begin(), ws);
+    c->ws = ws;
     return HCTR_OK;
 }
 
@@ -499,10 +528,14 @@ int check_forward_args(hctr_ctx* c, const void* img, int img_dtype, int B, int W
     return HCTR_OK;
 }
 
+// lines per internal pass: at most max_cols pixel columns, balanced so every pass of a batch has the
+// same shape (one cached workspace per (B, W) instead of a second one for a short tail)
 int sub_batch(hctr_ctx* c, int B, int W) {
     int64_t nb = c->max_cols / W;
     if (nb < 1) nb = 1;
-    return (int)std::min<int64_t>(nb, B);
+    if (nb >= B) return B;
+    const int64_t passes = (B + nb - 1) / nb;
+    return (int)((B + passes - 1) / passes);
 }
 
 }  // namespace
@@ -536,6 +569,10 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
         return fail(nullptr, HCTR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     if (const char* bt = getenv("HCTR_BIG_TILES")) c->big_tiles = atoi(bt) != 0;
+    if (const char* wb = getenv("HCTR_WS_BUDGET_GB")) {
+        const long long v = atoll(wb);
+        if (v > 0) c->ws_budget = (size_t)v << 30;
+    }
     if (const char* mc = getenv("HCTR_MAX_COLS")) {
         const long long v = atoll(mc);
         if (v > 0) c->max_cols = v;
@@ -548,7 +585,7 @@ void hctr_destroy(hctr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    free_pool(c->ws.allocs);
+    for (auto& w : c->ws_cache) free_pool(w.allocs);
     free_pool(c->wallocs);
     free_pool(c->beam_allocs);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

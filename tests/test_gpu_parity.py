@@ -265,3 +265,35 @@ def test_error_behaviour(pkg, synth, state_dict):
     m3 = pkg.hctr_model(100).cuda(0)
     with pytest.raises(RuntimeError):
         m3.load_state_dict(state_dict)                     # linear.weight shape mismatch
+
+
+def test_bucketed_mixed_widths_and_subbatches(pkg, engine, codec, synth, state_dict):
+    """Config-3 style: mixed widths through the bucketing helper; every bucket equals the oracle run on
+    that bucket with NormalizePAD semantics, and a batch split into internal passes (HCTR_MAX_COLS
+    forced small through a second context) gives bit-identical labels to the single-pass run."""
+    from importlib import import_module
+    import os
+    bk = import_module(pkg.__name__ + ".bucketing")
+    rng_w = [96, 96, 40, 41, 150, 147, 96, 33]
+    images = [synth.make_line_images(1, w, 300 + i)[0] for i, w in enumerate(rng_w)]
+    texts = bk.recognize(engine, codec, images, max_lines=3, max_pad_fraction=0.1)
+    assert all(isinstance(t, str) for t in texts)
+    oc = ctc_ref.CtcCodecRef(synth.characters())
+    for idx in bk.plan_batches(rng_w, 3, 0.1):
+        batch, ws = bk.pad_batch(images, idx)
+        logits = engine(batch, widths=ws)
+        ref = hctr_ref.forward(state_dict, synth.normalize_pad(batch, ws)).numpy()
+        assert np.abs(logits - ref).max() <= LOGIT_RTOL * np.abs(ref).max() + LOGIT_ATOL
+        assert [texts[i] for i in idx] == oc.decode(logits)          # bucketed result == per-batch result
+    # internal sub-batching: same labels whether the batch runs in one pass or several
+    imgs = synth.make_line_images(6, 64, 9)
+    one = engine.greedy(imgs)
+    os.environ["HCTR_MAX_COLS"] = "130"                              # 2 lines per pass at W=64
+    try:
+        small = pkg.hctr_model(synth.DEFAULT_VOCAB + 2).cuda(0)
+        small.load_state_dict(state_dict)
+    finally:
+        del os.environ["HCTR_MAX_COLS"]
+    many = small.greedy(imgs)
+    assert all(np.array_equal(a, b) for a, b in zip(one, many))
+    assert np.array_equal(small(imgs), engine(imgs))

@@ -203,3 +203,19 @@ def test_gather_world_size_2_gloo(tmp_path):
                          capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "GATHER_OK" in res.stdout
+
+
+def test_plan_batches(pkg):
+    from importlib import import_module
+    bk = import_module(pkg.__name__ + ".bucketing")
+    widths = [800] * 5 + [3200] * 3 + [1600] * 4 + [2400] * 2 + [3190]
+    plan = bk.plan_batches(widths, max_lines=4, max_pad_fraction=0.1)
+    flat = sorted(int(i) for b in plan for i in b)
+    assert flat == list(range(len(widths)))                      # every line exactly once
+    for b in plan:
+        ws = [widths[i] for i in b]
+        assert len(b) <= 4 and min(ws) >= 0.9 * max(ws)
+    assert [widths[i] for i in plan[0]] == [3200, 3200, 3200, 3190]   # widest first, near-equal grouped
+    imgs = [np.full((128, w), 7, np.uint8) for w in (5, 9, 9)]
+    batch, ws = bk.pad_batch(imgs, [1, 0])
+    assert batch.shape == (2, 128, 9) and ws.tolist() == [9, 5] and batch[1, 0, 5:].sum() == 0
