@@ -2,9 +2,9 @@
 //
 // Behavioural contract: utils/ctc_codec.py:124-285 and Beam :288-307 of the reference -
 // __cbs_full__, __cbs_skip__ and __context_beam_search__ - on the device front end's output
-// (log-softmax top-k, blank log-prob, thresholded candidate lists). Hypotheses are label-id
-// sequences instead of Python strings (the vocabulary is assumed duplicate-free, as the reference's
-// char->index dict also assumes). Everything that decides a tie is kept:
+// (log-softmax top-k, blank log-prob, thresholded candidate lists). Hypotheses are nodes of a
+// label-id prefix trie instead of Python strings (the vocabulary is assumed duplicate-free, as the
+// reference's char->index dict also assumes). Everything that decides a tie is kept:
 //   * scores are float64 sums of float32 log-probs, merged with numpy's logaddexp formula;
 //   * new hypotheses are created in first-touch order (Python dict insertion order, :233-265);
 //   * the cut to beam_size is a STABLE descending sort on total() (sorted(..., reverse=True), :283);
@@ -19,6 +19,7 @@
 #include <limits>
 #include <map>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -35,30 +36,66 @@ inline double logaddexp(double x, double y) {
     return tmp;   // NaN
 }
 
+// Prefixes live in a per-line trie: a hypothesis is a node id, extending a prefix is one hash lookup
+// and two prefixes are equal iff their node ids are (the reference compares/concatenates Python
+// strings of up to ~1000 characters at every step; same semantics, O(1) instead of O(length)).
+struct Node {
+    int parent;
+    int32_t label;      // -1 at the root
+    int len;
+    double toy;         // built-in toy LM: left-to-right running sum over this prefix's bigrams
+    uint32_t cp;        // code point of `label` (0 at the root)
+};
+
+struct Trie {
+    std::vector<Node> nodes;
+    std::unordered_map<uint64_t, int> kids;
+    const int32_t* cps;
+    explicit Trie(const int32_t* codepoints) : cps(codepoints) { nodes.push_back(Node{-1, -1, 0, 0.0, 0u}); }
+    // one bigram term of the deterministic toy LM (same formula as oracle/ctc_ref.py toy_bigram_score)
+    static double toy_term(uint64_t prev, uint64_t c) {
+        uint64_t h = (prev * 2654435761ull + c * 40503ull + 12345ull) & 0xFFFFFFFFull;
+        h ^= h >> 15;
+        h = (h * 2246822519ull) & 0xFFFFFFFFull;
+        h ^= h >> 13;
+        return -4.0 * ((double)(h & 0xFFFFull) / 65536.0);
+    }
+    int child(int node, int32_t label) {
+        const uint64_t key = ((uint64_t)(uint32_t)node << 32) | (uint32_t)label;
+        auto it = kids.find(key);
+        if (it != kids.end()) return it->second;
+        const Node p = nodes[node];
+        const uint32_t cp = cps ? (uint32_t)cps[label] : 0u;
+        nodes.push_back(Node{node, label, p.len + 1, cps ? p.toy + toy_term(p.cp, cp) : 0.0, cp});
+        kids.emplace(key, (int)nodes.size() - 1);
+        return (int)nodes.size() - 1;
+    }
+    void append_labels(int node, std::vector<int32_t>& out) const {      // root -> node order
+        const size_t at = out.size();
+        out.resize(at + nodes[node].len);
+        for (int n = node, i = nodes[node].len - 1; n > 0; n = nodes[n].parent, --i) out[at + i] = nodes[n].label;
+    }
+    // toy LM score of prefix(node) + suffix, summed left to right exactly like the oracle
+    double toy_score(int node, const std::vector<int32_t>& suffix) const {
+        double s = nodes[node].toy;
+        uint64_t prev = nodes[node].cp;
+        for (int32_t l : suffix) {
+            const uint64_t c = (uint32_t)cps[l];
+            s += toy_term(prev, c);
+            prev = c;
+        }
+        return s;
+    }
+};
+
 struct Hyp {
-    std::vector<int32_t> prefix;
+    int node;
     double pb, pnb, pt;
     double prob() const { return logaddexp(pb, pnb); }
     double total() const { return logaddexp(pb, pnb) + pt; }
 };
 
-inline Hyp fresh_hyp() { return Hyp{{}, 0.0, kNegInf, 0.0}; }      // Beam(), :289-297
-
-// deterministic toy bigram LM (same formula as oracle/ctc_ref.py toy_bigram_score)
-double toy_bigram(const int32_t* ids, int n, const int32_t* cps) {
-    double s = 0.0;
-    uint64_t prev = 0;
-    for (int i = 0; i < n; ++i) {
-        const uint64_t c = (uint64_t)(uint32_t)cps[ids[i]];
-        uint64_t h = (prev * 2654435761ull + c * 40503ull + 12345ull) & 0xFFFFFFFFull;
-        h ^= h >> 15;
-        h = (h * 2246822519ull) & 0xFFFFFFFFull;
-        h ^= h >> 13;
-        s += -4.0 * ((double)(h & 0xFFFFull) / 65536.0);
-        prev = c;
-    }
-    return s;
-}
+inline Hyp fresh_hyp() { return Hyp{0, 0.0, kNegInf, 0.0}; }      // Beam(), :289-297
 
 struct LineInput {
     int W, B, C, k, b;
@@ -71,38 +108,53 @@ struct LineInput {
     const float* full_logp;     // optional [W][B][C] log-probs (needed for LM-proposed candidates)
 };
 
+struct Scratch {                 // per line, reused across steps
+    std::vector<Hyp> gen;
+    std::vector<int> slot_of;    // node id -> index in gen for the current step (valid iff stamp matches)
+    std::vector<int> stamp;
+    int epoch = 0;
+    std::vector<int32_t> ids, offs, ling;
+    std::vector<double> scores, tot;
+    std::vector<int> order;
+};
+
 // one prefix-beam step (__context_beam_search__, :212-285). cands/plog: visual candidates and their
 // log-probs at this time step. Returns HCTR_OK or a callback failure code.
-int beam_step(const hctr_beam_params& P, const LineInput& in, int t, std::vector<Hyp>& beams,
+int beam_step(const hctr_beam_params& P, const LineInput& in, int t, Trie& trie, Scratch& S, std::vector<Hyp>& beams,
               const int32_t* cands, const float* plog, int ncand, const std::vector<int32_t>& suffix) {
     const int unk = in.C - 1;
     // Step 1: optional LM-proposed candidates per beam (:215-227)
-    std::vector<int32_t> ling;
     if (P.next_cb) {
-        std::vector<int32_t> ids, offs(1, 0);
+        S.ids.clear();
+        S.offs.assign(1, 0);
         for (const Hyp& h : beams) {
-            ids.insert(ids.end(), h.prefix.begin(), h.prefix.end());
-            offs.push_back((int32_t)ids.size());
+            trie.append_labels(h.node, S.ids);
+            S.offs.push_back((int32_t)S.ids.size());
         }
-        ling.assign((size_t)beams.size() * P.search_depth, 0);
-        const int rc = P.next_cb(P.user, (int)beams.size(), ids.data(), offs.data(), P.search_depth, ling.data());
+        S.ling.assign((size_t)beams.size() * P.search_depth, 0);
+        const int rc = P.next_cb(P.user, (int)beams.size(), S.ids.data(), S.offs.data(), P.search_depth, S.ling.data());
         if (rc != 0) return rc;
     }
-    // Step 2: extend (:229-265). gen keeps first-touch order; index maps prefix -> slot.
-    std::vector<Hyp> gen;
-    std::map<std::vector<int32_t>, int> index;
-    auto slot = [&](const std::vector<int32_t>& pre) -> int {
-        auto it = index.find(pre);
-        if (it != index.end()) return it->second;
-        gen.push_back(Hyp{pre, kNegInf, kNegInf, 0.0});
-        index.emplace(pre, (int)gen.size() - 1);
+    // Step 2: extend (:229-265). gen keeps first-touch order (Python dict insertion order).
+    std::vector<Hyp>& gen = S.gen;
+    gen.clear();
+    ++S.epoch;
+    auto slot = [&](int node) -> int {
+        if ((size_t)node >= S.stamp.size()) {
+            S.stamp.resize(trie.nodes.size() + 64, 0);
+            S.slot_of.resize(S.stamp.size(), 0);
+        }
+        if (S.stamp[node] == S.epoch) return S.slot_of[node];
+        S.stamp[node] = S.epoch;
+        S.slot_of[node] = (int)gen.size();
+        gen.push_back(Hyp{node, kNegInf, kNegInf, 0.0});
         return (int)gen.size() - 1;
     };
-    std::vector<int32_t> ext;
     for (size_t bi = 0; bi < beams.size(); ++bi) {
-        const Hyp& h = beams[bi];
+        const Hyp h = beams[bi];
         const double hprob = h.prob();
-        const int nl = (P.next_cb && !h.prefix.empty()) ? P.search_depth : 0;
+        const int tail = trie.nodes[h.node].label;               // -1 for the empty prefix
+        const int nl = (P.next_cb && h.node != 0) ? P.search_depth : 0;
         for (int ci = 0; ci < ncand + nl; ++ci) {
             int idx;
             double p;
@@ -110,21 +162,18 @@ int beam_step(const hctr_beam_params& P, const LineInput& in, int t, std::vector
                 idx = cands[ci];
                 p = (double)plog[ci];
             } else {
-                idx = ling[bi * P.search_depth + (ci - ncand)];
+                idx = S.ling[bi * P.search_depth + (ci - ncand)];
                 if (idx < 0 || idx >= in.C) return HCTR_ERR_ARG;
                 if (idx >= unk) continue;
                 p = (double)in.full_logp[((size_t)t * in.B + in.b) * in.C + idx];
             }
             if (idx >= unk) continue;                                  // ignore <unknown> (:238-239)
-            const int ps = slot(h.prefix);
+            const int ps = slot(h.node);
             if (idx == 0) {                                            // blank: only pb (:246-249)
                 gen[ps].pb = logaddexp(gen[ps].pb, hprob + p);
                 continue;
             }
-            const int tail = h.prefix.empty() ? -1 : h.prefix.back();
-            ext = h.prefix;
-            ext.push_back(idx);
-            const int es = slot(ext);
+            const int es = slot(trie.child(h.node, idx));
             if (idx != tail) {
                 gen[es].pnb = logaddexp(gen[es].pnb, hprob + p);        // (:256-258)
             } else {
@@ -134,37 +183,32 @@ int beam_step(const hctr_beam_params& P, const LineInput& in, int t, std::vector
         }
     }
     // Step 3: LM score + length bonus, stable sort, cut (:267-285)
-    if (!gen.empty()) {
-        std::vector<double> scores(gen.size(), 0.0);
+    const size_t n = gen.size();
+    if (n) {
+        S.scores.assign(n, 0.0);
         if (P.builtin_lm == 2) {
-            std::vector<int32_t> sent;
-            for (size_t i = 0; i < gen.size(); ++i) {
-                sent = gen[i].prefix;
-                sent.insert(sent.end(), suffix.begin(), suffix.end());
-                scores[i] = toy_bigram(sent.data(), (int)sent.size(), P.label_codepoints);
-            }
+            for (size_t i = 0; i < n; ++i) S.scores[i] = trie.toy_score(gen[i].node, suffix);
         } else if (P.builtin_lm == 0) {
-            std::vector<int32_t> ids, offs(1, 0);
+            S.ids.clear();
+            S.offs.assign(1, 0);
             for (const Hyp& g : gen) {
-                ids.insert(ids.end(), g.prefix.begin(), g.prefix.end());
-                ids.insert(ids.end(), suffix.begin(), suffix.end());
-                offs.push_back((int32_t)ids.size());
+                trie.append_labels(g.node, S.ids);
+                S.ids.insert(S.ids.end(), suffix.begin(), suffix.end());
+                S.offs.push_back((int32_t)S.ids.size());
             }
-            const int rc = P.score_cb(P.user, (int)gen.size(), ids.data(), offs.data(), scores.data());
+            const int rc = P.score_cb(P.user, (int)n, S.ids.data(), S.offs.data(), S.scores.data());
             if (rc != 0) return rc;
         }
-        for (size_t i = 0; i < gen.size(); ++i)
-            gen[i].pt = scores[i] * P.lm_panelty + (double)gen[i].prefix.size() * P.len_bonus;
+        for (size_t i = 0; i < n; ++i)
+            gen[i].pt = S.scores[i] * P.lm_panelty + (double)trie.nodes[gen[i].node].len * P.len_bonus;
     }
-    std::vector<double> tot(gen.size());
-    std::vector<int> order(gen.size());
-    for (size_t i = 0; i < gen.size(); ++i) { tot[i] = gen[i].total(); order[i] = (int)i; }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return tot[a] > tot[b]; });
-    const size_t keep = std::min<size_t>(order.size(), (size_t)std::max(P.beam_size, 0));
-    std::vector<Hyp> out;
-    out.reserve(keep);
-    for (size_t i = 0; i < keep; ++i) out.push_back(std::move(gen[order[i]]));
-    beams.swap(out);
+    S.tot.resize(n);
+    S.order.resize(n);
+    for (size_t i = 0; i < n; ++i) { S.tot[i] = gen[i].total(); S.order[i] = (int)i; }
+    std::stable_sort(S.order.begin(), S.order.end(), [&](int a, int b) { return S.tot[a] > S.tot[b]; });
+    const size_t keep = std::min<size_t>(n, (size_t)std::max(P.beam_size, 0));
+    beams.clear();
+    for (size_t i = 0; i < keep; ++i) beams.push_back(gen[S.order[i]]);
     return HCTR_OK;
 }
 
@@ -183,6 +227,8 @@ int decode_line(const hctr_beam_params& P, const LineInput& in, int32_t* out_lab
     if (line_lab.empty()) return HCTR_ERR_EMPTY_LINE;              // top_line[-1] -> IndexError (:143,198)
     int end_step = line_t.back() + 4;
     if (end_step >= W) end_step = W;
+    Trie trie(P.builtin_lm == 2 ? P.label_codepoints : nullptr);
+    Scratch S;
     std::vector<Hyp> beams(1, fresh_hyp());
     std::vector<int32_t> suffix;
     size_t first_after = 0;                                         // first greedy entry with ts > t
@@ -196,14 +242,14 @@ int decode_line(const hctr_beam_params& P, const LineInput& in, int32_t* out_lab
         };
         if (!P.skip_search) {
             make_suffix();
-            const int rc = beam_step(P, in, t, beams, in.topk_idx + r * k, in.topk_logp + r * k, depth, suffix);
+            const int rc = beam_step(P, in, t, trie, S, beams, in.topk_idx + r * k, in.topk_logp + r * k, depth, suffix);
             if (rc != HCTR_OK) return rc;
             continue;
         }
         const int64_t c0 = in.cand_off[r], n = in.cand_off[r + 1] - c0;
         if (n != 1) {
             make_suffix();
-            const int rc = beam_step(P, in, t, beams, in.cand_idx + c0, in.cand_logp + c0, (int)n, suffix);
+            const int rc = beam_step(P, in, t, trie, S, beams, in.cand_idx + c0, in.cand_logp + c0, (int)n, suffix);
             if (rc != HCTR_OK) return rc;
             continue;
         }
@@ -213,16 +259,16 @@ int decode_line(const hctr_beam_params& P, const LineInput& in, int32_t* out_lab
         const double pc = (double)in.cand_logp[c0];
         const double p0 = (double)in.blank_logp[r];
         for (Hyp& h : beams) {
-            const int tail = h.prefix.empty() ? -1 : h.prefix.back();
+            const int tail = trie.nodes[h.node].label;
             if (c == 0) {
                 h.pb = h.prob() + pc;                                 // pc == row[0] here
             } else if (c != tail) {
                 const double pr = h.prob();
-                h.prefix.push_back(c);
+                h.node = trie.child(h.node, c);
                 h.pnb = pr + pc;
                 h.pb = kNegInf;
             } else if (h.pb != kNegInf) {
-                h.prefix.push_back(c);
+                h.node = trie.child(h.node, c);
                 h.pnb = h.pb + pc;
                 h.pb = kNegInf;
             } else {
@@ -232,7 +278,8 @@ int decode_line(const hctr_beam_params& P, const LineInput& in, int32_t* out_lab
         }
     }
     if (beams.empty()) return HCTR_ERR_EMPTY_LINE;                  // kept_beams[0] -> IndexError (:179,208)
-    const std::vector<int32_t>& best = beams[0].prefix;
+    std::vector<int32_t> best;
+    trie.append_labels(beams[0].node, best);
     *out_len = (int32_t)best.size();
     if (!best.empty()) memcpy(out_labels, best.data(), best.size() * sizeof(int32_t));
     return HCTR_OK;
