@@ -30,8 +30,10 @@ SEED = 2
 FLOP_PER_COL_DOM = 75.497472e6        # one 3x3 512->512 @ H=16 layer, per pixel column
 FLOP_PER_COL_ALL = 1358.838912e6      # whole forward per pixel column at C=7358
 PEAK_F16_TFLOPS = 2500.0              # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
-DOMINANT = ("block3.1.conv1", "block3.1.conv2", "block3.2.conv1", "block3.2.conv2", "block3.3.conv1",
-            "block3.3.conv2", "block3.4.conv1", "block3.4.conv2", "block3.0.conv2", "conv3+pool")
+# the ten 3x3 512->512 @H=16 launches of a forward (conv2 is named "+se" when the SE apply is fused)
+DOMINANT = tuple(n + sfx for n in ("block3.0.conv2", "block3.1.conv2", "block3.2.conv2", "block3.3.conv2",
+                                   "block3.4.conv2") for sfx in ("", "+se")) + \
+    ("block3.1.conv1", "block3.2.conv1", "block3.3.conv1", "block3.4.conv1", "conv3+pool")
 
 
 def main():

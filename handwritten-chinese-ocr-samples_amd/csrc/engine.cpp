@@ -62,6 +62,8 @@ struct Workspace {
     float* logits = nullptr;        // [B*W][Cpad]
     float* se_part = nullptr;
     float* se_scale = nullptr;
+    float* se_border = nullptr;     // [B][4][512]
+    float* se_mean = nullptr;       // [B][512]
     int32_t* colidx = nullptr;      // [B*W]
     int32_t* labels = nullptr;      // [B][W]
     int32_t* lengths = nullptr;     // [B]
@@ -97,6 +99,7 @@ struct hctr_ctx {
     size_t ws_budget = (size_t)200 << 30;
     int64_t max_cols = kDefaultMaxCols;
     bool big_tiles = true;
+    bool fuse_se = true;
     // profiling
     bool profiling = false;
     std::vector<ProfEntry> prof;
@@ -343,6 +346,8 @@ int ensure_workspace(hctr_ctx* c, int B, int W) {
     A(&ws.logits, (size_t)cols * c->cpad, false);
     A(&ws.se_part, se_max, false);
     A(&ws.se_scale, (size_t)B * 512, false);
+    A(&ws.se_border, (size_t)B * 4 * 512, false);
+    A(&ws.se_mean, (size_t)B * 512, false);
     A(&ws.colidx, (size_t)cols, false);
     A(&ws.labels, (size_t)cols, false);
     A(&ws.lengths, (size_t)B, false);
@@ -396,10 +401,12 @@ ConvTile pick_tile(const hctr_ctx* c, const ConvW& cw, int H) {
 }
 
 int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc in, half_t* out, int outH,
-             bool relu, bool pool, float* se_part, bool to_head) {
+             bool relu, bool pool, float* se_part, bool to_head, const float* se_scale = nullptr,
+             const half_t* resid = nullptr) {
     const Workspace& ws = c->ws;
     ConvArgs a{};
     a.x = in.p; a.w = cw.w; a.bias = cw.bias; a.y = out; a.se_part = se_part;
+    a.se_scale = se_scale; a.resid = resid;
     a.H = in.H; a.W = ws.W; a.Cin = cw.cin; a.Cout = cw.cout; a.CoutPad = cw.coutPad;
     const ConvTile tile = pick_tile(c, cw, in.H);
     const int rows = conv_tile_rows(tile);
@@ -427,24 +434,41 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
     return HCTR_OK;
 }
 
-// BasicBlock.forward (models/handwritten_ctr_model.py:47-60)
+// BasicBlock.forward (models/handwritten_ctr_model.py:47-60). Fused form (default): the SE scale is
+// computed from statistics of conv1's output before conv2 runs (kernels.hip, se_premean), and conv2's
+// epilogue applies relu(acc * scale + residual) itself. HCTR_FUSE_SE=0 selects the unfused form
+// (conv2 -> o, SE on sums of o, separate se_apply pass) for A/B runs.
 int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, ActDesc in, half_t* t,
               half_t* o, half_t* r, int planes) {
     const Workspace& ws = c->ws;
     const int H = in.H;
-    TRY(run_conv(c, pf, (name + ".conv1").c_str(), bw.conv1, in, t, H, true, false, nullptr, false));
-    TRY(run_conv(c, pf, (name + ".conv2").c_str(), bw.conv2, ActDesc{t, H, planes}, o, H, false, false,
-                 ws.se_part, false));
-    const int tiles = (H / conv_tile_rows(pick_tile(c, bw.conv2, H))) * ((ws.W + kTileW - 1) / kTileW);
-    pf.begin((name + ".se_fc").c_str());
-    HIP_TRY(c, launch_se_fc(ws.se_part, tiles, bw.se.w1, bw.se.w2, ws.se_scale, ws.B, planes,
-                            1.0f / ((float)H * (float)ws.W), c->stream));
-    pf.end();
+    const int tilesW = (ws.W + kTileW - 1) / kTileW;
+    const float inv_hw = 1.0f / ((float)H * (float)ws.W);
     const half_t* res = in.p;
     if (bw.has_ds) {
         TRY(run_conv(c, pf, (name + ".downsample").c_str(), bw.ds, in, r, H, false, false, nullptr, false));
         res = r;
     }
+    if (c->fuse_se) {
+        const int tiles1 = (H / conv_tile_rows(pick_tile(c, bw.conv1, H))) * tilesW;
+        TRY(run_conv(c, pf, (name + ".conv1").c_str(), bw.conv1, in, t, H, true, false, ws.se_part, false));
+        pf.begin((name + ".se_stats").c_str());
+        HIP_TRY(c, launch_se_border(t, ws.B, H, ws.W, ws.Wa, planes, ws.se_border, c->stream));
+        HIP_TRY(c, launch_se_premean(ws.se_part, tiles1, ws.se_border, t, bw.conv2.w, bw.conv2.bias, ws.B, H, ws.W,
+                                     ws.Wa, planes, bw.conv2.coutPad, ws.se_mean, c->stream));
+        HIP_TRY(c, launch_se_fc(ws.se_mean, 1, bw.se.w1, bw.se.w2, ws.se_scale, ws.B, planes, 1.0f, c->stream));
+        pf.end();
+        TRY(run_conv(c, pf, (name + ".conv2+se").c_str(), bw.conv2, ActDesc{t, H, planes}, o, H, true, false, nullptr,
+                     false, ws.se_scale, res));
+        return HCTR_OK;
+    }
+    TRY(run_conv(c, pf, (name + ".conv1").c_str(), bw.conv1, in, t, H, true, false, nullptr, false));
+    TRY(run_conv(c, pf, (name + ".conv2").c_str(), bw.conv2, ActDesc{t, H, planes}, o, H, false, false,
+                 ws.se_part, false));
+    const int tiles = (H / conv_tile_rows(pick_tile(c, bw.conv2, H))) * tilesW;
+    pf.begin((name + ".se_fc").c_str());
+    HIP_TRY(c, launch_se_fc(ws.se_part, tiles, bw.se.w1, bw.se.w2, ws.se_scale, ws.B, planes, inv_hw, c->stream));
+    pf.end();
     pf.begin((name + ".se_apply").c_str());
     HIP_TRY(c, launch_se_apply(o, res, ws.se_scale, (int64_t)(H + 2) * ws.Wa * planes, ws.B, planes, c->stream));
     pf.end();
@@ -569,6 +593,7 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
         return fail(nullptr, HCTR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     if (const char* bt = getenv("HCTR_BIG_TILES")) c->big_tiles = atoi(bt) != 0;
+    if (const char* fs = getenv("HCTR_FUSE_SE")) c->fuse_se = atoi(fs) != 0;
     if (const char* wb = getenv("HCTR_WS_BUDGET_GB")) {
         const long long v = atoll(wb);
         if (v > 0) c->ws_budget = (size_t)v << 30;

@@ -18,7 +18,10 @@ struct ConvArgs {
     const half_t* w;        // [taps][CoutPad][Cin], rows permuted to MFMA order within 64-blocks
     const float* bias;      // [CoutPad] folded BatchNorm bias
     void* y;                // output base (fp16, or fp32 for the head)
-    float* se_part;         // [B][tilesH*tilesW][Cout] partial channel sums, or nullptr
+    float* se_part;         // [B][tilesH*tilesW][Cout] per-tile channel sums of the STORED (fp16-rounded,
+                            // post-ReLU, column-masked) outputs, or nullptr
+    const float* se_scale;  // fused squeeze-excite: [B][Cout] channel scales, or nullptr
+    const half_t* resid;    // fused residual (same geometry as the output), used with se_scale
     int H, W;               // conv output rows / valid columns (pre-pool)
     int Cin, Cout, CoutPad;
     int tilesW, tilesH;     // pixel tiles per image
@@ -45,6 +48,14 @@ size_t conv_lds_bytes(ConvTile tile);
 
 hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, const float* w9,
                        const float* bias, half_t* y, int B, int W, int Wa, hipStream_t s);
+
+// channel sums of the border rows / columns of a padded NHWC activation: out[b][4][C] =
+// {row 0, row H-1, column 0, column W-1}
+hipError_t launch_se_border(const half_t* t, int B, int H, int W, int Wa, int C, float* out, hipStream_t s);
+// SE mean of conv2(t) from the statistics of t (linearity of the convolution), see kernels.hip
+hipError_t launch_se_premean(const float* tsum_part, int tiles, const float* border, const half_t* t,
+                             const half_t* w, const float* bias, int B, int H, int W, int Wa, int C,
+                             int CoutPad, float* mean, hipStream_t s);
 
 hipError_t launch_se_fc(const float* se_part, int tiles_per_img, const float* w1, const float* w2,
                         float* scale, int B, int C, float inv_hw, hipStream_t s);

@@ -67,18 +67,64 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
 
     const int w = tw * kTileW + c;
     const bool wvalid = w < a.W;
+    const int hbase = th * (4 * WM) + wm * 4;
+    half_t* out = (half_t*)a.y;
+    const int64_t pix0 = a.out_off + img * a.out_sb + (int64_t)w * a.out_sw + cw0;
+
+    // fused squeeze-excite + residual (BasicBlock :54-58): acc = acc * scale[img][cout] + residual
+    if (a.se_scale != nullptr) {
+        const float* sc = a.se_scale + (int64_t)img * a.Cout + cw0;
+        if (w < a.out_wlimit) {
+            // all residual loads first (one latency exposure), 16 couts = 2 x 16 B per (cb, n)
+            f16x8 rlo[JT / 4][4], rhi[JT / 4][4];
+#pragma unroll
+            for (int cb = 0; cb < JT / 4; ++cb)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const half_t* r = a.resid + pix0 + (int64_t)(hbase + n) * a.out_sh + cb * 64;
+                    rlo[cb][n] = *(const f16x8*)r;
+                    rhi[cb][n] = *(const f16x8*)(r + 8);
+                }
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const f32x4 s4 = *(const f32x4*)(sc + (j >> 2) * 64 + (j & 3) * 4);
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = (j & 3) * 4 + i;
+                        const float r = e < 8 ? (float)rlo[j >> 2][n][e] : (float)rhi[j >> 2][n][e - 8];
+                        acc[j][n][i] = fmaf(acc[j][n][i], s4[i], r);
+                    }
+            }
+        }
+    }
+
+    // ReLU, column mask, fp16 rounding (in place: acc now holds exactly the values that are stored)
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = acc[j][n][i];
+                if (a.pool && (n & 1) == 0) v = fmaxf(v, acc[j][n + 1][i]);   // (2,1) max-pool -> even n
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (!wvalid) v = 0.f;
+                acc[j][n][i] = (float)(half_t)v;
+            }
 
     if (a.se_part != nullptr) {
-        // per-(image, channel) sums over this block's valid pixels, fixed reduction order
-        // (deterministic: lane tree -> LDS -> one partial row per block; reduced later by se_fc).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // PIPE: last (redundant) DMA has landed
+        // per-(image, channel) sums of the stored values over this block's pixels, fixed reduction
+        // order (deterministic: lane tree -> LDS -> one partial row per block; no float atomics).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a trailing LDS-DMA (if any) has landed
         __syncthreads();                       // main-loop LDS no longer needed
         float* red = (float*)smem;             // [WM][BN]
 #pragma unroll
         for (int j = 0; j < JT; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float s = wvalid ? (acc[j][0][i] + acc[j][1][i]) + (acc[j][2][i] + acc[j][3][i]) : 0.f;
+                float s = (acc[j][0][i] + acc[j][1][i]) + (acc[j][2][i] + acc[j][3][i]);
                 s += __shfl_xor(s, 1);
                 s += __shfl_xor(s, 2);
                 s += __shfl_xor(s, 4);
@@ -95,45 +141,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
         }
     }
 
-    half_t* out = (half_t*)a.y;
     if (w < a.out_wlimit) {
-        const int hbase = th * (4 * WM) + wm * 4;
-        half_t* obase = out + a.out_off + img * a.out_sb + (int64_t)w * a.out_sw + cw0;
-        if (a.pool) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                half_t* o = obase + (int64_t)((hbase >> 1) + p) * a.out_sh;
+        for (int n = 0; n < 4; ++n) {
+            if (a.pool && (n & 1)) continue;
+            const int ho = a.pool ? ((hbase + n) >> 1) : (hbase + n);
+            half_t* o = out + pix0 + (int64_t)ho * a.out_sh;
 #pragma unroll
-                for (int cb = 0; cb < JT / 4; ++cb) {
-                    f16x8 lo, hi;
+            for (int cb = 0; cb < JT / 4; ++cb) {
+                f16x8 lo, hi;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float v = fmaxf(acc[cb * 4 + (e >> 2)][2 * p][e & 3], acc[cb * 4 + (e >> 2)][2 * p + 1][e & 3]);
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        if (!wvalid) v = 0.f;
-                        if (e < 8) lo[e] = (half_t)v; else hi[e - 8] = (half_t)v;
-                    }
-                    *(f16x8*)(o + cb * 64) = lo;
-                    *(f16x8*)(o + cb * 64 + 8) = hi;
+                for (int e = 0; e < 16; ++e) {
+                    const half_t hv = (half_t)acc[cb * 4 + (e >> 2)][n][e & 3];
+                    if (e < 8) lo[e] = hv; else hi[e - 8] = hv;
                 }
-            }
-        } else {
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                half_t* o = obase + (int64_t)(hbase + n) * a.out_sh;
-#pragma unroll
-                for (int cb = 0; cb < JT / 4; ++cb) {
-                    f16x8 lo, hi;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float v = acc[cb * 4 + (e >> 2)][n][e & 3];
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        if (!wvalid) v = 0.f;
-                        if (e < 8) lo[e] = (half_t)v; else hi[e - 8] = (half_t)v;
-                    }
-                    *(f16x8*)(o + cb * 64) = lo;
-                    *(f16x8*)(o + cb * 64 + 8) = hi;
-                }
+                *(f16x8*)(o + cb * 64) = lo;
+                *(f16x8*)(o + cb * 64 + 8) = hi;
             }
         }
     }
@@ -645,6 +668,126 @@ hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, 
     const int64_t grid = (npix + 31) / 32;
     hipLaunchKernelGGL(stem_kernel, dim3((unsigned)grid), dim3(256), 0, s, img, img_f32, widths_dev, w9,
                        bias, y, B, W, Wa);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------
+// Squeeze-excite mean WITHOUT materialising conv2's output first.
+// SELayer needs mean_{h,w}(bn2(conv2(t))) (models/handwritten_ctr_model.py:27,51-53). The convolution is
+// linear, so with S_tap[ci] = sum over output positions of t[h+dy][w+dx][ci] (zero outside the image)
+//     mean[c] = bias[c] + (1/HW) * sum_tap sum_ci W[tap][c][ci] * S_tap[ci],
+// and S_tap follows from nine statistics of t per (image, channel): the total T, the sums of row 0,
+// row H-1, column 0, column W-1 and the four corner values:
+//     S(dy,dx) = T - [dy=+1] R0 - [dy=-1] RL - [dx=+1] C0 - [dx=-1] CL + corner(dy,dx)   (if dy,dx != 0)
+// T comes from conv1's epilogue (per-tile sums of the stored fp16 values), the rest from se_border
+// below and four direct reads. The scale is then known BEFORE conv2 runs, so conv2's epilogue applies
+// relu(acc * scale + residual) itself and the separate read-o/read-r/write pass disappears.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se_border_kernel(const half_t* __restrict__ t, int H, int W, int Wa, int C,
+                                                        float* __restrict__ out) {
+    __shared__ float red[256 * 8];
+    const int b = blockIdx.x, job = blockIdx.y;        // 0: row 0, 1: row H-1, 2: col 0, 3: col W-1
+    const int cv = C >> 3;                             // 16-byte vectors per pixel
+    const int v = threadIdx.x % cv, lanes = 256 / cv, p0 = threadIdx.x / cv;
+    const half_t* img = t + (int64_t)b * (H + 2) * Wa * C;
+    const int count = job < 2 ? W : H;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (threadIdx.x < lanes * cv)
+        for (int p = p0; p < count; p += lanes) {
+            const int h = job == 0 ? 0 : (job == 1 ? H - 1 : p);
+            const int w = job == 2 ? 0 : (job == 3 ? W - 1 : p);
+            const f16x8 x = *(const f16x8*)(img + ((int64_t)(h + 1) * Wa + (w + 1)) * C + v * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)x[e];
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < cv) {                            // fixed-order reduction over the position lanes
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int l = 0; l < lanes; ++l)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += red[(l * cv + threadIdx.x) * 8 + e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[((int64_t)b * 4 + job) * C + threadIdx.x * 8 + e] = s[e];
+    }
+}
+
+hipError_t launch_se_border(const half_t* t, int B, int H, int W, int Wa, int C, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(se_border_kernel, dim3(B, 4), dim3(256), 0, s, t, H, W, Wa, C, out);
+    return hipGetLastError();
+}
+
+// one block per (image, 64 output channels); 4 k-slices x 64 couts per block
+__global__ __launch_bounds__(256) void se_premean_kernel(const float* __restrict__ tsum_part, int tiles,
+                                                         const float* __restrict__ border,
+                                                         const half_t* __restrict__ t,
+                                                         const half_t* __restrict__ w,
+                                                         const float* __restrict__ bias, int H, int W, int Wa,
+                                                         int C, int CoutPad, float* __restrict__ mean) {
+    __shared__ float S[9 * 512];
+    const int b = blockIdx.x, cg = blockIdx.y;
+    const half_t* img = t + (int64_t)b * (H + 2) * Wa * C;
+    for (int ci = threadIdx.x; ci < C; ci += 256) {
+        const float* p = tsum_part + (int64_t)b * tiles * C + ci;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int i = 0;
+        for (; i + 3 < tiles; i += 4) {
+            s0 += p[(int64_t)i * C]; s1 += p[(int64_t)(i + 1) * C];
+            s2 += p[(int64_t)(i + 2) * C]; s3 += p[(int64_t)(i + 3) * C];
+        }
+        for (; i < tiles; ++i) s0 += p[(int64_t)i * C];
+        const float T = (s0 + s1) + (s2 + s3);
+        const float* bd = border + (int64_t)b * 4 * C + ci;
+        const float R0 = bd[0], RL = bd[C], C0 = bd[2 * C], CL = bd[3 * C];
+        const float t00 = (float)img[((int64_t)1 * Wa + 1) * C + ci];
+        const float t0L = (float)img[((int64_t)1 * Wa + W) * C + ci];
+        const float tL0 = (float)img[((int64_t)H * Wa + 1) * C + ci];
+        const float tLL = (float)img[((int64_t)H * Wa + W) * C + ci];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            float sv = T;
+            if (dy == 1) sv -= R0;
+            if (dy == -1) sv -= RL;
+            if (dx == 1) sv -= C0;
+            if (dx == -1) sv -= CL;
+            if (dy == 1 && dx == 1) sv += t00;
+            if (dy == 1 && dx == -1) sv += t0L;
+            if (dy == -1 && dx == 1) sv += tL0;
+            if (dy == -1 && dx == -1) sv += tLL;
+            S[tap * C + ci] = sv;
+        }
+    }
+    __syncthreads();
+    // cout c = cg*64 + cl is stored row blk*64 + s with perm64(s) = cl (engine.cpp perm64)
+    const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int qq = cl >> 4, rem = cl & 15, jj = rem >> 2, ii = rem & 3;
+    const int srow = jj * 16 + qq * 4 + ii;
+    float acc = 0.f;
+    const int kper = 9 * C / 4;                        // this slice's share of the 9*C reduction
+    for (int kk = slice * kper; kk < (slice + 1) * kper; kk += 8) {
+        const int tap = kk / C, ci = kk - tap * C;
+        const f16x8 wv8 = *(const f16x8*)(w + ((int64_t)tap * CoutPad + cg * 64 + srow) * C + ci);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf((float)wv8[e], S[tap * C + ci + e], acc);
+    }
+    __shared__ float part[256];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const float tot = (part[threadIdx.x] + part[64 + threadIdx.x]) + (part[128 + threadIdx.x] + part[192 + threadIdx.x]);
+        const int c = cg * 64 + threadIdx.x;
+        mean[(int64_t)b * C + c] = bias[c] + tot / ((float)H * (float)W);
+    }
+}
+
+hipError_t launch_se_premean(const float* tsum_part, int tiles, const float* border, const half_t* t,
+                             const half_t* w, const float* bias, int B, int H, int W, int Wa, int C,
+                             int CoutPad, float* mean, hipStream_t s) {
+    if (C > 512 || C % 64 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(se_premean_kernel, dim3(B, C / 64), dim3(256), 0, s, tsum_part, tiles, border, t, w, bias, H, W,
+                       Wa, C, CoutPad, mean);
     return hipGetLastError();
 }
 
