@@ -62,10 +62,18 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     dist = None
+    # Test hook (rehearsing the N > 1 flow on a 1-GPU box): HCTR_BENCH_BACKEND=gloo shares the visible
+    # GPUs round-robin between ranks and gathers over gloo. The driver's runs use RCCL ("nccl").
+    backend = os.environ.get("HCTR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
     dev = torch.device("cuda", local)
 
     C = synth.DEFAULT_VOCAB + 2
@@ -81,11 +89,13 @@ def main():
     imgs = torch.from_numpy(imgs_host).to(dev)              # resident in HBM before timing
     torch.cuda.synchronize(dev)
     n_global = B * world
+    import importlib
+    gather = importlib.import_module(hctr_amd.package.__name__ + ".dist").gather_labels
 
     def step():
         labels = model.greedy(imgs)
         if dist is not None:
-            return hctr_amd.package.dist.gather_labels(labels, n_global, W, device=dev)
+            return gather(labels, n_global, W, device=dev if backend == "nccl" else None)
         return labels
 
     for _ in range(args.warmup):
@@ -106,7 +116,7 @@ def main():
     dt = time.perf_counter() - t0
     model.set_profiling(False)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

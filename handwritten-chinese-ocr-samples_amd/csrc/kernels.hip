@@ -472,27 +472,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvArgs a) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            // next K step's weights (clamped on the very last step: re-stages into the idle buffer)
-            {
-                int kc1 = kc, tap1 = tap + 1;
-                if (tap1 == 9) { tap1 = 0; kc1 = next_chunk ? kc + 1 : kc; }
-                if (a.dbg == 1) { kc1 = 0; tap1 = 0; }
-                if (a.dbg != 2) stage_weights(kc1, tap1, (k + 1) & 1);
-            }
-            // next chunk's halo: piece (wv + 8*tap) on steps 0..5 (branch-free select of the offset)
-            {
-                uint32_t ho = hoff[0];
-                ho = tap == 1 ? hoff[1] : ho;
-                ho = tap == 2 ? hoff[2] : ho;
-                ho = tap == 3 ? hoff[3] : ho;
-                ho = tap == 4 ? hoff[4] : ho;
-                ho = tap == 5 ? hoff[5] : ho;
-                if (next_chunk && tap < 6 && wv + 8 * tap < kHaloPieces && a.dbg != 2) {   // tap 5: waves 0..4
-                    const char* src = xbase + (int64_t)(a.dbg == 1 ? 0 : kc + 1) * (kBK * 2);
-                    char* dst = smem + 65536 + ((kc + 1) & 1) * kHaloBytes + (wv + 8 * tap) * 1024;
-                    glds16_asm(src + ho, dst);
-                }
-            }
             // B fragments: halo pixel row index hr = (wm*4 + n + 1 + dy)*20 + (c + 1 + dx); swizzle key
             // hr & 7 = ((c+1+dx) & 7) ^ 4*((n+1+dy) & 1)  (20 = 4 mod 8, +4 mod 8 = ^4). With the chunk
             // index ks*4 + q, the four (ks, n parity) cases need only two per-lane offsets, v0 and v0^64.
@@ -523,6 +502,30 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvArgs a) {
             read_a(0, ar[0]);
             __builtin_amdgcn_sched_barrier(0);
             read_a(1, ar[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            // The DMA of the next step is issued AFTER the first fragment reads so its issue cost overlaps
+            // their LDS latency (the asm DMA is invisible to the compiler's waitcnt bookkeeping).
+            // next K step's weights (clamped on the very last step: re-stages into the idle buffer)
+            {
+                int kc1 = kc, tap1 = tap + 1;
+                if (tap1 == 9) { tap1 = 0; kc1 = next_chunk ? kc + 1 : kc; }
+                if (a.dbg == 1) { kc1 = 0; tap1 = 0; }
+                if (a.dbg != 2) stage_weights(kc1, tap1, (k + 1) & 1);
+            }
+            // next chunk's halo: piece (wv + 8*tap) on steps 0..5 (branch-free select of the offset)
+            {
+                uint32_t ho = hoff[0];
+                ho = tap == 1 ? hoff[1] : ho;
+                ho = tap == 2 ? hoff[2] : ho;
+                ho = tap == 3 ? hoff[3] : ho;
+                ho = tap == 4 ? hoff[4] : ho;
+                ho = tap == 5 ? hoff[5] : ho;
+                if (next_chunk && tap < 6 && wv + 8 * tap < kHaloPieces && a.dbg != 2) {   // tap 5: waves 0..4
+                    const char* src = xbase + (int64_t)(a.dbg == 1 ? 0 : kc + 1) * (kBK * 2);
+                    char* dst = smem + 65536 + ((kc + 1) & 1) * kHaloBytes + (wv + 8 * tap) * 1024;
+                    glds16_asm(src + ho, dst);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {

@@ -297,3 +297,48 @@ def test_bucketed_mixed_widths_and_subbatches(pkg, engine, codec, synth, state_d
     many = small.greedy(imgs)
     assert all(np.array_equal(a, b) for a, b in zip(one, many))
     assert np.array_equal(small(imgs), engine(imgs))
+
+
+def test_cli_reference_flags(tmp_path, engine, codec, synth):
+    """test.py drop-in CLI (reference flags test.py:24-106): folder inference with greedy and beam
+    decode, and -bm benchmark mode computing CER over <input>/test_img_id_gt.txt."""
+    import ast
+    import subprocess
+    import sys
+    from PIL import Image
+    from conftest import ROOT
+    data = tmp_path / "data"
+    (data / "test").mkdir(parents=True)
+    widths = [90, 64, 90, 77]
+    imgs = [synth.make_line_images(1, w, 500 + i)[0] for i, w in enumerate(widths)]
+    want = []
+    for i, im in enumerate(imgs):
+        Image.fromarray(im).save(data / "test" / ("%06d.png" % i))
+    for i in range(0, 4, 2):                                  # the CLI batches files in sorted order, -b 2
+        w = max(widths[i:i + 2])
+        batch = np.zeros((2, 128, w), np.uint8)
+        for j in range(2):
+            batch[j, :, :widths[i + j]] = imgs[i + j]
+        want += codec.labels_to_text(engine.greedy(batch, widths=np.array(widths[i:i + 2], np.int32)))
+    with open(data / "test_img_id_gt.txt", "w", encoding="utf-8") as f:
+        for i, t in enumerate(want):
+            f.write("%06d.png,%s\n" % (i, t if i != 3 else t[:-1] + "?"))     # one deliberate error
+    base = [sys.executable, os.path.join(ROOT, "test.py"), "-m", "hctr", "-f", "synthetic", "-b", "2"]
+    r = subprocess.run(base + ["-i", str(data / "test"), "-dm", "greedy-search"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = []
+    for line in r.stdout.splitlines():
+        if line.startswith("predicted results: "):
+            got += ast.literal_eval(line[len("predicted results: "):])
+    assert got == want
+    r = subprocess.run(base + ["-i", str(data), "-dm", "greedy-search", "-bm"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cer = float([l for l in r.stdout.splitlines() if l.startswith("Total Test CER:")][0].split()[3])
+    nchar = sum(len(t) for t in want)
+    assert abs(cer - 1.0 / nchar) < 1e-9
+    r = subprocess.run(base + ["-i", str(data / "test"), "-dm", "beam-search", "-kp", "toy", "-ss", "-bs", "5"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count("predicted results: ") == 2
