@@ -413,16 +413,22 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvArgs a) {
     // halo origin = padded pixel (th*16, tw*16) = output pixel (th*16 - 1, tw*16 - 1)
     const char* xbase = (const char*)(a.x + img * a.in_sb + (int64_t)(th * 16) * a.in_sh + (int64_t)(tw * 16) * cin);
     const char* wbase = (const char*)(a.w + (int64_t)n0 * cin);
-    uint32_t woff[4], hoff[6];
+    // Asymmetric staging: only waves 0..3 issue LDS-DMA (8 weight pieces per K step + 2 halo pieces on
+    // the first six steps of a chunk, each); their SIMD partners 4..7 go straight to their fragment
+    // reads and MFMAs after the barrier, so the matrix pipe runs the partner's work while the loader
+    // wave pays the DMA issue cost, then the loader's own.
+    const bool loader = wv < 4;
+    uint32_t woff[8], hoff[12];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int g = (wv * 4 + i) * 64 + lane;
+    for (int i = 0; i < 8; ++i) {
+        const int g = ((wv & 3) * 8 + i) * 64 + lane;
         const int row = g >> 3, cp = (g & 7) ^ (row & 7);
         woff[i] = (uint32_t)row * (uint32_t)cin * 2u + cp * 16;
     }
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        const int g = (wv + 8 * r) * 64 + lane;            // piece wv + 8r
+    for (int r = 0; r < 12; ++r) {                          // piece ((r>>1)*4 + wv)*2 + (r&1), step r>>1
+        const int piece = ((r >> 1) * 4 + (wv & 3)) * 2 + (r & 1);
+        const int g = piece * 64 + lane;
         const int row = g >> 3, cp = (g & 7) ^ (row & 7);
         int hy = row / kHaloCols, hx = row - hy * kHaloCols;
         if (hx > 17) hx = 17;                               // pad columns: any valid address
@@ -435,15 +441,15 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvArgs a) {
 
     auto stage_weights = [&](int kc, int tap, int buf) {
         const char* src = wbase + ((int64_t)tap * a.CoutPad * cin + (int64_t)kc * kBK) * 2;
-        char* dst = smem + buf * 32768 + (wv * 4) * 1024;
+        char* dst = smem + buf * 32768 + ((wv & 3) * 8) * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
             glds16_asm(src + woff[i], dst + i * 1024);
     };
-    auto stage_halo_piece = [&](int kc, int buf, int r, uint32_t off) {
-        if (wv + 8 * r < kHaloPieces) {                     // wave-uniform
+    auto stage_halo_piece = [&](int kc, int buf, int piece, uint32_t off) {
+        if (piece < kHaloPieces) {                          // wave-uniform
             const char* src = xbase + (int64_t)kc * (kBK * 2);
-            char* dst = smem + 65536 + buf * kHaloBytes + (wv + 8 * r) * 1024;
+            char* dst = smem + 65536 + buf * kHaloBytes + piece * 1024;
             glds16_asm(src + off, dst);
         }
     };
@@ -454,9 +460,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvArgs a) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    if (loader) {
 #pragma unroll
-    for (int r = 0; r < 6; ++r) stage_halo_piece(0, 0, r, hoff[r]);
-    stage_weights(0, 0, 0);
+        for (int r = 0; r < 12; ++r) stage_halo_piece(0, 0, ((r >> 1) * 4 + wv) * 2 + (r & 1), hoff[r]);
+        stage_weights(0, 0, 0);
+    }
 
     for (int kc = 0; kc < nkc; ++kc) {
         const bool next_chunk = kc + 1 < nkc;
@@ -464,11 +472,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvArgs a) {
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int k = kc * 9 + tap;
-            // Retire the previous step's DMA. Steps 0..4 of a chunk issue (after the 4 weight pieces) one
-            // piece of the NEXT chunk's halo from every wave; that piece is cold (HBM) and not needed for
-            // several steps, so it may stay in flight across this barrier: vmcnt(1) retires everything
-            // older (vmcnt counts in issue order). All other steps drain completely.
-            if (tap >= 1 && tap <= 5 && next_chunk) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            // Retire the previous step's DMA. Steps 0..4 of a chunk issue (after the 8 weight pieces) two
+            // pieces of the NEXT chunk's halo from every loader wave; they are cold (HBM) and not needed
+            // for several steps, so they may stay in flight across this barrier: vmcnt(2) retires
+            // everything older (vmcnt counts in issue order). All other steps drain completely.
+            if (tap >= 1 && tap <= 5 && next_chunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -505,25 +513,24 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             // The DMA of the next step is issued AFTER the first fragment reads so its issue cost overlaps
             // their LDS latency (the asm DMA is invisible to the compiler's waitcnt bookkeeping).
-            // next K step's weights (clamped on the very last step: re-stages into the idle buffer)
-            {
+            if (loader) {
+                // next K step's weights (clamped on the very last step: re-stages into the idle buffer)
                 int kc1 = kc, tap1 = tap + 1;
                 if (tap1 == 9) { tap1 = 0; kc1 = next_chunk ? kc + 1 : kc; }
                 if (a.dbg == 1) { kc1 = 0; tap1 = 0; }
                 if (a.dbg != 2) stage_weights(kc1, tap1, (k + 1) & 1);
-            }
-            // next chunk's halo: piece (wv + 8*tap) on steps 0..5 (branch-free select of the offset)
-            {
-                uint32_t ho = hoff[0];
-                ho = tap == 1 ? hoff[1] : ho;
-                ho = tap == 2 ? hoff[2] : ho;
-                ho = tap == 3 ? hoff[3] : ho;
-                ho = tap == 4 ? hoff[4] : ho;
-                ho = tap == 5 ? hoff[5] : ho;
-                if (next_chunk && tap < 6 && wv + 8 * tap < kHaloPieces && a.dbg != 2) {   // tap 5: waves 0..4
-                    const char* src = xbase + (int64_t)(a.dbg == 1 ? 0 : kc + 1) * (kBK * 2);
-                    char* dst = smem + 65536 + ((kc + 1) & 1) * kHaloBytes + (wv + 8 * tap) * 1024;
-                    glds16_asm(src + ho, dst);
+                // next chunk's halo: two pieces per loader wave on steps 0..5 (branch-free offset select)
+                if (next_chunk && tap < 6 && a.dbg != 2) {
+                    uint32_t h0 = hoff[0], h1 = hoff[1];
+                    h0 = tap == 1 ? hoff[2] : h0;  h1 = tap == 1 ? hoff[3] : h1;
+                    h0 = tap == 2 ? hoff[4] : h0;  h1 = tap == 2 ? hoff[5] : h1;
+                    h0 = tap == 3 ? hoff[6] : h0;  h1 = tap == 3 ? hoff[7] : h1;
+                    h0 = tap == 4 ? hoff[8] : h0;  h1 = tap == 4 ? hoff[9] : h1;
+                    h0 = tap == 5 ? hoff[10] : h0; h1 = tap == 5 ? hoff[11] : h1;
+                    const int p0 = (tap * 4 + wv) * 2;
+                    const int kcs = a.dbg == 1 ? 0 : kc + 1;
+                    stage_halo_piece(kcs, (kc + 1) & 1, p0, h0);
+                    stage_halo_piece(kcs, (kc + 1) & 1, p0 + 1, h1);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
