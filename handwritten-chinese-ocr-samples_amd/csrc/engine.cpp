@@ -452,10 +452,14 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
     if (c->fuse_se) {
         const int tiles1 = (H / conv_tile_rows(pick_tile(c, bw.conv1, H))) * tilesW;
         TRY(run_conv(c, pf, (name + ".conv1").c_str(), bw.conv1, in, t, H, true, false, ws.se_part, false));
-        pf.begin((name + ".se_stats").c_str());
+        pf.begin((name + ".se_border").c_str());
         HIP_TRY(c, launch_se_border(t, ws.B, H, ws.W, ws.Wa, planes, ws.se_border, c->stream));
+        pf.end();
+        pf.begin((name + ".se_premean").c_str());
         HIP_TRY(c, launch_se_premean(ws.se_part, tiles1, ws.se_border, t, bw.conv2.w, bw.conv2.bias, ws.B, H, ws.W,
                                      ws.Wa, planes, bw.conv2.coutPad, ws.se_mean, c->stream));
+        pf.end();
+        pf.begin((name + ".se_fc").c_str());
         HIP_TRY(c, launch_se_fc(ws.se_mean, 1, bw.se.w1, bw.se.w2, ws.se_scale, ws.B, planes, 1.0f, c->stream));
         pf.end();
         TRY(run_conv(c, pf, (name + ".conv2+se").c_str(), bw.conv2, ActDesc{t, H, planes}, o, H, true, false, nullptr,

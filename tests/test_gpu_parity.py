@@ -342,3 +342,56 @@ def test_cli_reference_flags(tmp_path, engine, codec, synth):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.count("predicted results: ") == 2
+
+
+@pytest.mark.parametrize("B,W", [(1, 1), (2, 5), (1, 16), (3, 17)])
+def test_tiny_and_odd_widths(engine, codec, synth, state_dict, B, W):
+    """Edge shapes: widths below / just above the 16-column tile, single column."""
+    imgs = synth.make_line_images(B, max(W, 8), 900 + W)[:, :, :W]
+    imgs = np.ascontiguousarray(imgs)
+    got = engine(imgs)
+    ref = hctr_ref.forward(state_dict, synth.normalize_pad(imgs)).numpy()
+    assert got.shape == ref.shape == (W, B, synth.DEFAULT_VOCAB + 2)
+    assert np.abs(got - ref).max() <= LOGIT_RTOL * np.abs(ref).max() + LOGIT_ATOL
+    fused = codec.labels_to_text(engine.greedy(imgs))
+    assert fused == codec.decode(got)
+
+
+def test_empty_batch(engine, synth):
+    out = engine(np.zeros((0, 128, 40), np.uint8))
+    assert out.shape == (40, 0, synth.DEFAULT_VOCAB + 2)
+    assert engine.greedy(np.zeros((0, 128, 40), np.uint8)) == []
+
+
+def test_other_vocabulary_size_and_checkpoint_file(tmp_path, pkg, synth):
+    """A 100-character vocabulary (C=102, head padded to 256) loaded from a real ``.pth.tar`` checkpoint
+    file in the reference's format (main.py:349-356), through the model API and through test.py."""
+    import subprocess
+    import sys
+    import torch
+    from PIL import Image
+    from conftest import ROOT
+    C = 102
+    sd = synth.make_state_dict(C, seed=3)
+    ckpt = tmp_path / "hctr_checkpoint.pth.tar"
+    torch.save({"epoch": 1, "state_dict": synth.to_torch(sd), "best_acc": 0.0, "optimizer": {}}, str(ckpt))
+    m = pkg.hctr_model(C).cuda(0)
+    m.load_state_dict(torch.load(str(ckpt), map_location="cpu", weights_only=True)["state_dict"])
+    imgs = synth.make_line_images(2, 70, 77)
+    got = m(imgs)
+    ref = hctr_ref.forward(sd, synth.normalize_pad(imgs)).numpy()
+    assert got.shape == (70, 2, C)
+    assert np.abs(got - ref).max() <= LOGIT_RTOL * np.abs(ref).max() + LOGIT_ATOL
+    chars = synth.characters(C - 2)
+    cd = pkg.ctc_codec(chars).attach(m)
+    want = cd.labels_to_text(m.greedy(imgs[:1]))
+    data = tmp_path / "set" / "test"
+    data.mkdir(parents=True)
+    Image.fromarray(imgs[0]).save(data / "a.png")
+    with open(tmp_path / "set" / "chars_list.txt", "w", encoding="utf-8") as f:   # test.py:315-326 discovery
+        f.write(chars + "\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "test.py"), "-m", "hctr", "-f", str(ckpt), "-i", str(data),
+                        "-dm", "greedy-search"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Model output classes: 102" in r.stdout
+    assert ("predicted results: %r" % want) in r.stdout

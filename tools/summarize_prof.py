@@ -17,7 +17,8 @@ import sys
 def short(name):
     name = name.replace("void hctr::", "").replace("hctr::", "").replace("(hctr::ConvArgs)", "")
     if name.startswith("_ZN4hctr"):
-        for k in ("se_apply_kernel", "stem_kernel", "row_topk_kernel"):
+        for k in ("se_apply_kernel", "stem_kernel", "row_topk_kernel", "se_border_kernel", "se_premean_kernel",
+                  "log_softmax_rows_kernel", "row_candidates_kernel"):
             if k in name:
                 return k
     return name.split("(")[0][:44]
