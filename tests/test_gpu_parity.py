@@ -372,7 +372,7 @@ def test_other_vocabulary_size_and_checkpoint_file(tmp_path, pkg, synth):
     from PIL import Image
     from conftest import ROOT
     C = 102
-    sd = synth.make_state_dict(C, seed=3)
+    sd = synth.make_state_dict(C, seed=0)        # seed 0: the BN calibration data belongs to this trunk
     ckpt = tmp_path / "hctr_checkpoint.pth.tar"
     torch.save({"epoch": 1, "state_dict": synth.to_torch(sd), "best_acc": 0.0, "optimizer": {}}, str(ckpt))
     m = pkg.hctr_model(C).cuda(0)
