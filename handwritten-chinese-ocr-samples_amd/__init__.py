@@ -11,7 +11,7 @@ plus ``synth`` (deterministic synthetic checkpoints / line images) and ``build``
 """
 from . import synth  # noqa: F401
 from ._lib import build, load as load_library  # noqa: F401
-from .codec import ToyBigramLM, ZeroLM, ctc_codec  # noqa: F401
+from .codec import ArpaLM, ToyBigramLM, ZeroLM, ctc_codec  # noqa: F401
 from .model import hctr_model  # noqa: F401
 
-__all__ = ["hctr_model", "ctc_codec", "ZeroLM", "ToyBigramLM", "synth", "build", "load_library"]
+__all__ = ["hctr_model", "ctc_codec", "ZeroLM", "ToyBigramLM", "ArpaLM", "synth", "build", "load_library"]

@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(PKG_DIR, "libhctr_hip.so")
 HEADER = os.path.join(ROOT, "include", "hctr_hip.h")
 
 # (source, extra flags). beam_search.cpp must not contract a*b+c (bit-parity with Python floats).
-SOURCES = [("kernels.hip", []), ("engine.cpp", ["-x", "hip"]), ("beam_search.cpp", ["-ffp-contract=off"])]
+SOURCES = [("kernels.hip", []), ("engine.cpp", ["-x", "hip"]), ("beam_search.cpp", ["-ffp-contract=off"]),
+           ("ngram_lm.cpp", ["-ffp-contract=off"])]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 HCTR_OK = 0
@@ -28,7 +29,8 @@ def _stale():
     if not os.path.isfile(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, "kernels.h"), HEADER]
+    deps = [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, "kernels.h"),
+                                                          os.path.join(CSRC, "ngram_lm.h"), HEADER]
     return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
 
 
@@ -72,7 +74,7 @@ class BeamParams(ctypes.Structure):
                 ("lm_panelty", ctypes.c_double), ("len_bonus", ctypes.c_double),
                 ("builtin_lm", ctypes.c_int), ("label_codepoints", ctypes.c_void_p),
                 ("score_cb", LM_SCORE_CB), ("next_cb", LM_NEXT_CB), ("user", ctypes.c_void_p),
-                ("num_threads", ctypes.c_int)]
+                ("num_threads", ctypes.c_int), ("ngram", ctypes.c_void_p), ("label_words", ctypes.c_void_p)]
 
 
 # every symbol include/hctr_hip.h declares: (name, restype, argtypes)
@@ -92,6 +94,12 @@ SIGNATURES = [
     ("hctr_log_softmax", _I, [_VP, _VP, _I, _I, _I, _I, _VP]),
     ("hctr_beam_search", _I, [ctypes.POINTER(BeamParams), _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                               _VP, _VP, _VP]),
+    ("hctr_ngram_load", _I, [ctypes.c_char_p, ctypes.POINTER(_VP)]),
+    ("hctr_ngram_free", None, [_VP]),
+    ("hctr_ngram_order", _I, [_VP]),
+    ("hctr_ngram_word_id", ctypes.c_int32, [_VP, ctypes.c_char_p]),
+    ("hctr_ngram_score", ctypes.c_double, [_VP, ctypes.c_char_p, _I, _I]),
+    ("hctr_ngram_last_error", ctypes.c_char_p, []),
     ("hctr_set_profiling", _I, [_VP, _I]),
     ("hctr_last_profile", _I, [_VP, ctypes.c_char_p, _I, c_f32p, _I]),
     ("hctr_debug_activation", _I64, [_VP, ctypes.c_char_p, _VP, _I64, ctypes.POINTER(_I), ctypes.POINTER(_I)]),

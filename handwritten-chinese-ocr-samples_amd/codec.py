@@ -47,6 +47,36 @@ class ToyBigramLM(object):
         return s
 
 
+class ArpaLM(object):
+    """ARPA back-off n-gram model scored natively (csrc/ngram_lm.cpp) with the interface the reference
+    expects from ``kenlm.Model``: ``score(sentence, bos=True, eos=True)`` = log10 probability of a
+    space-separated sentence. Beam search uses it without Python callbacks (multi-threaded)."""
+
+    def __init__(self, arpa_path):
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        rc = lib.hctr_ngram_load(str(arpa_path).encode("utf-8"), ctypes.byref(h))
+        if rc != 0:
+            raise OSError("cannot load ARPA model: %s" % lib.hctr_ngram_last_error().decode("utf-8", "replace"))
+        self._h = h
+        self.path = str(arpa_path)
+        self.order = lib.hctr_ngram_order(h)
+
+    def score(self, sentence, bos=True, eos=True):
+        return float(_lib.load().hctr_ngram_score(self._h, sentence.encode("utf-8"), int(bos), int(eos)))
+
+    def word_id(self, token):
+        return int(_lib.load().hctr_ngram_word_id(self._h, token.encode("utf-8")))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.load().hctr_ngram_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 class ctc_codec(object):
     """ Convert between text-label and text-index """
 
@@ -195,6 +225,14 @@ class ctc_codec(object):
         lm = self.transformer if use_tfm_score else self.ngram
         if not use_tfm_score and isinstance(lm, ZeroLM):
             params.builtin_lm = 1
+        elif not use_tfm_score and isinstance(lm, ArpaLM):
+            params.builtin_lm = 3
+            unk = lm.word_id("<unk>")                    # OOV labels take <unk>'s id (as kenlm's vocabulary does)
+            words = np.array([(lm.word_id(c) if lm.word_id(c) >= 0 else unk) if len(c) == 1 else unk
+                              for c in chars], dtype=np.int32)
+            keep.append(words)
+            params.ngram = lm._h
+            params.label_words = words.ctypes.data
         elif not use_tfm_score and isinstance(lm, ToyBigramLM):
             params.builtin_lm = 2
             cps = np.array([ord(c) if len(c) == 1 else 0 for c in chars], dtype=np.int32)
@@ -292,6 +330,8 @@ class ctc_codec(object):
                 self.ngram = ZeroLM()
             elif ngram_path in ('toy', 'builtin:toy'):
                 self.ngram = ToyBigramLM()
+            elif str(ngram_path).lower().endswith(".arpa"):
+                self.ngram = ArpaLM(ngram_path)           # native ARPA scorer, no kenlm needed
             elif self.ngram is None or ngram_path:
                 import kenlm                              # same optional dependency as the reference
                 self.ngram = kenlm.Model(ngram_path)

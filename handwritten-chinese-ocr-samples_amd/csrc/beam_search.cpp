@@ -11,6 +11,7 @@
 //   * the skip variant updates beams in place with neither merge nor re-sort (:147-171).
 // Build with -ffp-contract=off so a*b+c is never fused (Python evaluates it unfused).
 #include "../../include/hctr_hip.h"
+#include "ngram_lm.h"
 
 #include <algorithm>
 #include <atomic>
@@ -43,15 +44,28 @@ struct Node {
     int parent;
     int32_t label;      // -1 at the root
     int len;
-    double toy;         // built-in toy LM: left-to-right running sum over this prefix's bigrams
-    uint32_t cp;        // code point of `label` (0 at the root)
+    double toy;         // built-in LMs: left-to-right running score of this prefix (toy bigram or n-gram)
+    uint32_t cp;        // toy LM: code point of `label` (0 at the root); n-gram LM: its word id
 };
 
 struct Trie {
     std::vector<Node> nodes;
     std::unordered_map<uint64_t, int> kids;
     const int32_t* cps;
-    explicit Trie(const int32_t* codepoints) : cps(codepoints) { nodes.push_back(Node{-1, -1, 0, 0.0, 0u}); }
+    const hctr_ngram* lm = nullptr;       // built-in ARPA LM (cps then maps label -> word id)
+    explicit Trie(const int32_t* codepoints, const hctr_ngram* ngram = nullptr) : cps(codepoints), lm(ngram) {
+        nodes.push_back(Node{-1, -1, 0, 0.0, 0u});
+    }
+    // the last (order-1) word ids of prefix(node), oldest first, preceded by <s> when the prefix is short
+    int lm_context(int node, int32_t* ctx) const {
+        const int want = hctr::ngram_order(lm) - 1;
+        int n = 0;
+        int32_t rev[16];
+        for (int nd = node; nd > 0 && n < want; nd = nodes[nd].parent) rev[n++] = (int32_t)nodes[nd].cp;
+        if (n < want && hctr::ngram_bos(lm) >= 0) rev[n++] = hctr::ngram_bos(lm);
+        for (int i = 0; i < n; ++i) ctx[i] = rev[n - 1 - i];
+        return n;
+    }
     // one bigram term of the deterministic toy LM (same formula as oracle/ctc_ref.py toy_bigram_score)
     static double toy_term(uint64_t prev, uint64_t c) {
         uint64_t h = (prev * 2654435761ull + c * 40503ull + 12345ull) & 0xFFFFFFFFull;
@@ -66,7 +80,15 @@ struct Trie {
         if (it != kids.end()) return it->second;
         const Node p = nodes[node];
         const uint32_t cp = cps ? (uint32_t)cps[label] : 0u;
-        nodes.push_back(Node{node, label, p.len + 1, cps ? p.toy + toy_term(p.cp, cp) : 0.0, cp});
+        double sc = 0.0;
+        if (lm) {
+            int32_t ctx[16];
+            const int n = lm_context(node, ctx);
+            sc = p.toy + hctr::ngram_word_logp(lm, ctx, n, (int32_t)cp);
+        } else if (cps) {
+            sc = p.toy + toy_term(p.cp, cp);
+        }
+        nodes.push_back(Node{node, label, p.len + 1, sc, cp});
         kids.emplace(key, (int)nodes.size() - 1);
         return (int)nodes.size() - 1;
     }
@@ -74,6 +96,19 @@ struct Trie {
         const size_t at = out.size();
         out.resize(at + nodes[node].len);
         for (int n = node, i = nodes[node].len - 1; n > 0; n = nodes[n].parent, --i) out[at + i] = nodes[n].label;
+    }
+    // n-gram score of prefix(node) + suffix: the cached prefix score, then the suffix words in order
+    double ngram_score(int node, const std::vector<int32_t>& suffix) const {
+        double s = nodes[node].toy;
+        int32_t ctx[32];
+        int n = lm_context(node, ctx);
+        for (int32_t l : suffix) {
+            const int32_t w = cps[l];
+            s += hctr::ngram_word_logp(lm, ctx, n, w);
+            if (n == 31) { memmove(ctx, ctx + 1, 30 * sizeof(int32_t)); n = 30; }
+            ctx[n++] = w;
+        }
+        return s;
     }
     // toy LM score of prefix(node) + suffix, summed left to right exactly like the oracle
     double toy_score(int node, const std::vector<int32_t>& suffix) const {
@@ -188,6 +223,8 @@ int beam_step(const hctr_beam_params& P, const LineInput& in, int t, Trie& trie,
         S.scores.assign(n, 0.0);
         if (P.builtin_lm == 2) {
             for (size_t i = 0; i < n; ++i) S.scores[i] = trie.toy_score(gen[i].node, suffix);
+        } else if (P.builtin_lm == 3) {
+            for (size_t i = 0; i < n; ++i) S.scores[i] = trie.ngram_score(gen[i].node, suffix);
         } else if (P.builtin_lm == 0) {
             S.ids.clear();
             S.offs.assign(1, 0);
@@ -227,7 +264,8 @@ int decode_line(const hctr_beam_params& P, const LineInput& in, int32_t* out_lab
     if (line_lab.empty()) return HCTR_ERR_EMPTY_LINE;              // top_line[-1] -> IndexError (:143,198)
     int end_step = line_t.back() + 4;
     if (end_step >= W) end_step = W;
-    Trie trie(P.builtin_lm == 2 ? P.label_codepoints : nullptr);
+    Trie trie(P.builtin_lm == 2 ? P.label_codepoints : (P.builtin_lm == 3 ? P.label_words : nullptr),
+              P.builtin_lm == 3 ? P.ngram : nullptr);
     Scratch S;
     std::vector<Hyp> beams(1, fresh_hyp());
     std::vector<int32_t> suffix;
@@ -298,7 +336,8 @@ extern "C" int hctr_beam_search(const hctr_beam_params* p, int W, int B, int C, 
     if (p->skip_search && (!cand_off || (cand_off[(size_t)W * B] > 0 && (!cand_idx || !cand_logp)))) return HCTR_ERR_ARG;
     if (p->builtin_lm == 0 && !p->score_cb) return HCTR_ERR_ARG;
     if (p->builtin_lm == 2 && !p->label_codepoints) return HCTR_ERR_ARG;
-    if (p->builtin_lm < 0 || p->builtin_lm > 2) return HCTR_ERR_ARG;
+    if (p->builtin_lm == 3 && (!p->ngram || !p->label_words)) return HCTR_ERR_ARG;
+    if (p->builtin_lm < 0 || p->builtin_lm > 3) return HCTR_ERR_ARG;
     if (p->next_cb && !full_logp_wbc) return HCTR_ERR_ARG;
     if (p->search_depth < 1 || p->beam_size < 0) return HCTR_ERR_ARG;
     const bool callbacks = p->builtin_lm == 0 || p->next_cb != nullptr;

@@ -119,13 +119,27 @@ int hctr_log_softmax(hctr_ctx* ctx, const float* logits_wbc, int on_device, int 
  *   next_cb:  optional (use_tfm_pred): for n beam prefixes fill out_ids[n][k] with the LM's k most
  *             likely next labels (utils/ctc_codec.py:216-227); NULL disables.
  * builtin_lm: 0 = callbacks, 1 = zero LM, 2 = toy hashed bigram over code points (needs
- *             label_codepoints[C]); built-ins make the multi-threaded path callback-free.
+ *             label_codepoints[C]), 3 = ARPA n-gram (needs ngram + label_words[C]); built-ins make
+ *             the multi-threaded path callback-free.
  * full_logp_wbc: float32 [W][B][C] log-probs, required only with next_cb (LM-proposed labels can be
  *             any class); NULL otherwise. cand_* are required only when skip_search != 0.
  * Per-line results: out_labels int32 [B][W] + out_lengths [B]. line_status[b] is HCTR_OK or
  * HCTR_ERR_EMPTY_LINE; the return value is the first non-OK line status. */
 typedef int (*hctr_lm_score_cb)(void* user, int n, const int32_t* ids, const int32_t* offs, double* scores);
 typedef int (*hctr_lm_next_cb)(void* user, int n, const int32_t* ids, const int32_t* offs, int k, int32_t* out_ids);
+
+/* ---- ARPA back-off n-gram LM: stands in for kenlm.Model (utils/ctc_codec.py:121-122,276-281) ---
+ * hctr_ngram_score == kenlm.Model.score(sentence, bos, eos): log10 probability of a whitespace-
+ * separated UTF-8 sentence (Katz back-off, OOV -> <unk>). hctr_ngram_word_id maps a token to the
+ * model's word id (-1 = out of vocabulary) so the beam search can score label sequences natively
+ * (hctr_beam_params.builtin_lm == 3, .ngram, .label_words). Parity with the kenlm binary: unpinned. */
+typedef struct hctr_ngram hctr_ngram;
+int hctr_ngram_load(const char* arpa_path, hctr_ngram** out);
+void hctr_ngram_free(hctr_ngram* lm);
+int hctr_ngram_order(const hctr_ngram* lm);
+int32_t hctr_ngram_word_id(const hctr_ngram* lm, const char* word_utf8);
+double hctr_ngram_score(const hctr_ngram* lm, const char* sentence_utf8, int bos, int eos);
+const char* hctr_ngram_last_error(void);
 
 typedef struct {
     int skip_search;        /* utils/ctc_codec.py:40,66 */
@@ -139,6 +153,8 @@ typedef struct {
     hctr_lm_next_cb next_cb;
     void* user;
     int num_threads;        /* lines in parallel; forced to 1 when callbacks are used */
+    const hctr_ngram* ngram;          /* builtin_lm == 3: ARPA model ... */
+    const int32_t* label_words;       /* ... and [C] LM word id per label (-1 = OOV) */
 } hctr_beam_params;
 
 int hctr_beam_search(const hctr_beam_params* p, int W, int B, int C, int k,

@@ -64,3 +64,32 @@ BEAM_SETTINGS = [
     ("skip_toy", True, "toy", 0.8, 4.8, 5, 6),
     ("full_toy_narrow", False, "toy", 1.9, 5.7, 3, 4),
 ]
+
+
+def write_toy_arpa(path, n_chars=14, seed=7):
+    """Deterministic 3-gram ARPA over the first ``n_chars`` synthetic characters (+ <s>, </s>, <unk>),
+    with only SOME bigrams/trigrams present so every back-off branch is exercised."""
+    chars = list(vocab(n_chars + 2))
+    words = ["<unk>", "<s>", "</s>"] + chars
+    u = synth.uniform01(seed, 909, 4096)
+    ui = [0]
+
+    def nxt():
+        ui[0] += 1
+        return float(u[ui[0]])
+    uni = [(w, -1.0 - 3.0 * nxt(), -0.2 - 0.6 * nxt()) for w in words]
+    bi = [(a, b, -0.3 - 2.0 * nxt(), -0.1 - 0.5 * nxt()) for a in words[1:] for b in words[2:]
+          if a != "</s>" and nxt() < 0.45]
+    tri = [(a, b, c, -0.2 - 1.5 * nxt()) for (a, b, _, _) in bi for c in words[2:] if b != "</s>" and nxt() < 0.25]
+    with open(path, "w", encoding="utf-8") as f:
+        f.write("\\data\\\nngram 1=%d\nngram 2=%d\nngram 3=%d\n\n\\1-grams:\n" % (len(uni), len(bi), len(tri)))
+        for w, p, b in uni:
+            f.write("%.6f\t%s\t%.6f\n" % (p, w, b) if w != "</s>" else "%.6f\t%s\n" % (p, w))
+        f.write("\n\\2-grams:\n")
+        for a, b, p, bo in bi:
+            f.write("%.6f\t%s %s\t%.6f\n" % (p, a, b, bo))
+        f.write("\n\\3-grams:\n")
+        for a, b, c, p in tri:
+            f.write("%.6f\t%s %s %s\n" % (p, a, b, c))
+        f.write("\n\\end\\\n")
+    return path

@@ -342,6 +342,11 @@ def test_cli_reference_flags(tmp_path, engine, codec, synth):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.count("predicted results: ") == 2
+    arpa = codec_cases.write_toy_arpa(str(tmp_path / "toy.arpa"))                  # -kp model.arpa: native LM
+    r = subprocess.run(base + ["-i", str(data / "test"), "-dm", "beam-search", "-kp", arpa], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count("predicted results: ") == 2
 
 
 @pytest.mark.parametrize("B,W", [(1, 1), (2, 5), (1, 16), (3, 17)])

@@ -219,3 +219,63 @@ def test_plan_batches(pkg):
     imgs = [np.full((128, w), 7, np.uint8) for w in (5, 9, 9)]
     batch, ws = bk.pad_batch(imgs, [1, 0])
     assert batch.shape == (2, 128, 9) and ws.tolist() == [9, 5] and batch[1, 0, 5:].sum() == 0
+
+
+def test_arpa_ngram_scorer(pkg, tmp_path):
+    """csrc/ngram_lm.cpp vs the oracle's independent ARPA scorer and a hand-computed back-off case
+    (kenlm.Model.score semantics: log10, <s> context, eos optional, OOV -> <unk>)."""
+    from oracle import ctc_ref
+    # hand-made model: P(b|a) present, P(c|a b) absent -> backs off via bow(a b) [absent: 0] to P(c|b)
+    # [absent] -> bow(b) + P(c)
+    arpa = tmp_path / "hand.arpa"
+    arpa.write_text("\\data\\\nngram 1=6\nngram 2=2\nngram 3=1\n\n\\1-grams:\n"
+                    "-2.0\t<unk>\n-1.5\t<s>\t-0.5\n-1.2\t</s>\n-0.7\ta\t-0.3\n-0.9\tb\t-0.25\n-1.1\tc\t-0.1\n\n"
+                    "\\2-grams:\n-0.4\t<s> a\t-0.2\n-0.6\ta b\t-0.15\n\n\\3-grams:\n-0.05\t<s> a b\n\n\\end\\\n",
+                    encoding="utf-8")
+    lm = pkg.ArpaLM(str(arpa))
+    assert lm.order == 3
+    # <s> a b c : P(a|<s>) = -0.4 ; P(b|<s> a) = -0.05 (trigram) ; P(c|a b): no "a b c", bow(a b) = -0.15,
+    # no "b c", bow(b) = -0.25, P(c) = -1.1  => -1.5
+    assert abs(lm.score("a b c", eos=False) - (-0.4 - 0.05 - 0.15 - 0.25 - 1.1)) < 1e-6
+    assert abs(lm.score("a", bos=False, eos=False) - (-0.7)) < 1e-6
+    assert abs(lm.score("zzz", bos=False, eos=False) - (-2.0)) < 1e-6             # OOV -> <unk>
+    # </s> after "<s> a": no "<s> a </s>" -> bow(<s> a) = -0.2; no "a </s>" -> bow(a) = -0.3; P(</s>) = -1.2
+    assert abs(lm.score("a", eos=True) - (-0.4 - 0.2 - 0.3 - 1.2)) < 1e-6
+    ref = ctc_ref.ArpaRef(str(arpa))
+    for sent in ("a b c", "c c a b", "", "b zzz a", "a a a a a"):
+        for bos in (True, False):
+            for eos in (True, False):
+                assert abs(lm.score(sent, bos=bos, eos=eos) - ref.score(sent, bos=bos, eos=eos)) < 1e-9, (sent, bos, eos)
+    toy = codec_cases.write_toy_arpa(str(tmp_path / "toy.arpa"))
+    lm, ref = pkg.ArpaLM(toy), ctc_ref.ArpaRef(toy)
+    chars = codec_cases.vocab(18)
+    rng = np.random.RandomState(3)
+    for _ in range(200):
+        sent = " ".join(chars[i] for i in rng.randint(0, 16, size=rng.randint(0, 12)))
+        assert abs(lm.score(sent, eos=False) - ref.score(sent, eos=False)) < 1e-9
+    with pytest.raises(OSError):
+        pkg.ArpaLM(str(tmp_path / "missing.arpa"))
+
+
+def test_beam_search_with_native_arpa_lm(pkg, tmp_path):
+    """Beam search with the built-in ARPA model (threaded, no callbacks) == the oracle codec driven by
+    the oracle ARPA scorer == the same model through the Python callback path. Exact strings."""
+    from oracle import ctc_ref
+    toy = codec_cases.write_toy_arpa(str(tmp_path / "toy.arpa"))
+    c = 16
+    chars = codec_cases.vocab(c)
+    for seed, w, style, skip in ((21, 60, "mixed", False), (22, 45, "flat", False), (23, 60, "mixed", True)):
+        logits = codec_cases.gen_logits(seed, w, 2, c, style)
+        oc = ctc_ref.CtcCodecRef(chars)
+        oc.use_beam_search, oc.use_tfm_pred, oc.skip_search = True, False, skip
+        oc.lm_panelty, oc.len_bonus, oc.ngram = 0.8, 4.8, ctc_ref.ArpaRef(toy)
+        want = oc.decode(logits)
+        fe = _frontend_numpy(logits, 10)
+        for lm in (pkg.ArpaLM(toy), ctc_ref.ArpaRef(toy)):      # native builtin path, callback path
+            cd = pkg.ctc_codec(chars)
+            cd.use_beam_search, cd.use_tfm_pred, cd.skip_search = True, False, skip
+            cd.lm_panelty, cd.len_bonus, cd.ngram = 0.8, 4.8, lm
+            assert cd.decode_frontend(fe) == want, (seed, type(lm).__name__)
+    cd = pkg.ctc_codec(chars)
+    cd.set_beam_search(ngram_path=toy, use_tfm_pred=False, lm_panelty=0.8, len_bonus=4.8)   # -kp file.arpa
+    assert isinstance(cd.ngram, pkg.ArpaLM)
