@@ -556,6 +556,169 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvArgs a) {
     conv_epilogue<WN, WM, JT, false>(a, acc, smem, tid, lane, wn, wm, n0, mt, img, th, tw);
 }
 
+// -------------------------------------------------------------------------------------------
+// conv3x3_halo4: the same halo-reuse scheme as conv3x3_halo_kernel, but as a 4-wave workgroup
+// (128 couts x 16x16 pixels, each wave 128 couts x 64 pixels) with 2 x 16 KB weight buffers and ONE
+// 45 KB halo buffer = 77 KB of LDS, so TWO workgroups share a CU. The two waves on a SIMD then
+// belong to different workgroups with independent barriers and drift out of phase, which hides
+// the per-step barrier / DMA-latency bubble that the 8-wave lockstep structure exposes (SQ counters,
+// DESIGN.md). The halo of the next chunk can only be fetched after the last tap of the current one
+// (single buffer); the partner workgroup covers that stall.
+// -------------------------------------------------------------------------------------------
+constexpr int kHalo4Lds = 2 * 16384 + kHaloBytes;          // 78848
+
+__global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a) {
+    constexpr int WN = 1, WM = 4, JT = 8, BN = 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv;
+
+    const int total = a.mtiles * a.ntiles;
+    int lin;
+    {
+        const int id = blockIdx.x, xcd = id & 7, s = id >> 3;
+        const int q = total >> 3, r = total & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + s;
+    }
+    const int nt = lin % a.ntiles;
+    const int mt = lin / a.ntiles;
+    const int n0 = nt * BN;
+    const int tw = mt % a.tilesW;
+    const int t2 = mt / a.tilesW;
+    const int th = t2 % a.tilesH;
+    const int img = t2 / a.tilesH;
+    const int cin = a.Cin;
+    const int nkc = cin / kBK;
+
+    const char* xbase = (const char*)(a.x + img * a.in_sb + (int64_t)(th * 16) * a.in_sh + (int64_t)(tw * 16) * cin);
+    const char* wbase = (const char*)(a.w + (int64_t)n0 * cin);
+    uint32_t woff[4], hoff[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = (wv * 4 + i) * 64 + lane;
+        const int row = g >> 3, cp = (g & 7) ^ (row & 7);
+        woff[i] = (uint32_t)row * (uint32_t)cin * 2u + cp * 16;
+    }
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {                          // piece wv + 4r
+        const int g = (wv + 4 * r) * 64 + lane;
+        const int row = g >> 3, cp = (g & 7) ^ (row & 7);
+        int hy = row / kHaloCols, hx = row - hy * kHaloCols;
+        if (hx > 17) hx = 17;
+        if (hy > 17) hy = 17;
+        hoff[r] = ((uint32_t)hy * (uint32_t)a.in_sh + (uint32_t)hx * (uint32_t)cin) * 2u + cp * 16;
+    }
+    const int q = lane >> 4, c = lane & 15;
+    const int aoff0 = c * 128 + (((0 + q) ^ (lane & 7)) << 4);
+    const int aoff1 = c * 128 + (((4 + q) ^ (lane & 7)) << 4);
+
+    auto stage_weights = [&](int kc, int tap, int buf) {
+        const char* src = wbase + ((int64_t)tap * a.CoutPad * cin + (int64_t)kc * kBK) * 2;
+        char* dst = smem + buf * 16384 + (wv * 4) * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_asm(src + woff[i], dst + i * 1024);
+    };
+    auto stage_halo = [&](int kc) {
+        const char* src = xbase + (int64_t)kc * (kBK * 2);
+#pragma unroll
+        for (int r = 0; r < 12; ++r)
+            if (wv + 4 * r < kHaloPieces) glds16_asm(src + hoff[r], smem + 32768 + (wv + 4 * r) * 1024);
+    };
+
+    f32x4 acc[JT][4];
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    stage_halo(0);
+    stage_weights(0, 0, 0);
+    const int hbuf = 32768 + (wm * 4) * (kHaloCols * 128);
+
+    for (int kc = 0; kc < nkc; ++kc) {
+        const bool next_chunk = kc + 1 < nkc;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int k = kc * 9 + tap;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int tdy = tap / 3, dx = tap - tdy * 3 - 1;
+            const int u = c + 1 + dx;
+            const int v0 = u * 128 + (((q ^ (u & 7) ^ ((tdy & 1) << 2)) & 7) << 4);
+            const char* hb = smem + hbuf + tdy * (kHaloCols * 128);
+            const char* be = hb + v0;
+            const char* bo = hb + (v0 ^ 64);
+            const char* wt = smem + (k & 1) * 16384;
+            f16x8 ar[3][2], bq[2][4];
+            auto read_a = [&](int g, f16x8 (&dst)[2]) {
+                const int ks = g >> 2, jp = g & 3;
+                const char* base = wt + (ks ? aoff1 : aoff0);
+                dst[0] = *(const f16x8*)(base + (2 * jp) * 2048);
+                dst[1] = *(const f16x8*)(base + (2 * jp + 1) * 2048);
+            };
+            auto read_b = [&](int ks, f16x8 (&dst)[4]) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    dst[n] = *(const f16x8*)((((n & 1) ^ ks) ? bo : be) + n * (kHaloCols * 128));
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            read_b(0, bq[0]);
+            read_a(0, ar[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(1, ar[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            {   // next K step's weights (clamped on the very last step: re-stages into the idle buffer)
+                int kc1 = kc, tap1 = tap + 1;
+                if (tap1 == 9) { tap1 = 0; kc1 = next_chunk ? kc + 1 : kc; }
+                stage_weights(kc1, tap1, (k + 1) & 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int ks = g >> 2, jp = g & 3;
+                if (g + 2 < 8) read_a(g + 2, ar[(g + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g == 1) { read_b(1, bq[1]); __builtin_amdgcn_sched_barrier(0); }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[2 * jp + jj][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[g % 3][jj], bq[ks][n],
+                                                                                    acc[2 * jp + jj][n], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (next_chunk) {
+            // single halo buffer: every wave has consumed its last B fragments of this chunk (they fed the
+            // MFMAs above), so after this barrier the buffer may be overwritten with the next chunk.
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            stage_halo(kc + 1);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last (redundant) weight DMA has landed
+    conv_epilogue<WN, WM, JT, false>(a, acc, smem, tid, lane, 0, wm, n0, mt, img, th, tw);
+}
+
+static hipError_t launch_conv_halo4(const ConvArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           kHalo4Lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    ConvArgs b = a;
+    b.ntiles = a.CoutPad / 128;                             // 128-cout tiles
+    hipLaunchKernelGGL(conv3x3_halo4_kernel, dim3(b.mtiles * b.ntiles), dim3(256), kHalo4Lds, s, b);
+    return hipGetLastError();
+}
+
 static hipError_t launch_conv_halo(const ConvArgs& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -595,7 +758,8 @@ static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
 
 hipError_t launch_conv(const ConvArgs& a, ConvTile tile, int taps, bool linear_f32, hipStream_t s) {
     const size_t lds = conv_lds_bytes(tile);
-    static const bool halo = [] { const char* e = getenv("HCTR_HALO"); return e ? atoi(e) != 0 : true; }();
+    // HCTR_HALO: 0 = generic kernel, 1 = 8-wave halo kernel, 2 = two 4-wave halo workgroups per CU
+    static const int halo = [] { const char* e = getenv("HCTR_HALO"); return e ? atoi(e) : 2; }();
     static const bool pipe = [] { const char* e = getenv("HCTR_PIPE"); return e ? atoi(e) != 0 : false; }();
     if (linear_f32) {
         if (tile == TILE_256x256)
@@ -607,6 +771,7 @@ hipError_t launch_conv(const ConvArgs& a, ConvTile tile, int taps, bool linear_f
             return taps == 9 ? launch_conv_t<1, 4, 4, 9, false, false>(a, lds, s)
                              : launch_conv_t<1, 4, 4, 1, false, false>(a, lds, s);
         case TILE_256x256:
+            if (taps == 9 && halo == 2) return launch_conv_halo4(a, s);
             if (taps == 9 && halo) return launch_conv_halo(a, s);
             if (taps == 9)
                 return pipe ? launch_conv_t<2, 4, 8, 9, false, true>(a, lds, s)
