@@ -99,6 +99,7 @@ struct hctr_ctx {
     size_t ws_budget = (size_t)200 << 30;
     int64_t max_cols = kDefaultMaxCols;
     bool big_tiles = true;
+    int halo_mode = 2;
     bool fuse_se = true;
     // profiling
     bool profiling = false;
@@ -311,8 +312,8 @@ int ensure_workspace(hctr_ctx* c, int B, int W) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     Workspace ws;
     ws.B = B; ws.W = W;
-    const int tilesW = (W + kTileW - 1) / kTileW;
-    const int Wa = tilesW * kTileW + 2;
+    const int tilesW = (W + kTileW - 1) / kTileW;        // 16-column tiles (upper bound on tiles per row)
+    const int Wa = (W + 31) / 32 * 32 + 2;               // room for the widest (32-column) tile + border
     ws.Wa = Wa;
     const int64_t cols = (int64_t)B * W;
     // estimate, then evict least-recently-used workspaces until the new one fits the budget
@@ -396,6 +397,9 @@ struct ActDesc {            // a padded NHWC activation
 // the layer shape allows (Cout % 256 == 0, H % 16 == 0: stages 2 and 3 = 82 % of the FLOPs).
 ConvTile pick_tile(const hctr_ctx* c, const ConvW& cw, int H) {
     if (cw.cout == 64) return TILE_64x256;
+    // 3x3 layers with Cout % 128 == 0 and H % 16 == 0 (stages 1-3): two 4-wave halo workgroups per CU
+    if (c->halo_mode == 2 && cw.taps == 9 && cw.coutPad % 128 == 0 && H % 16 == 0) return TILE_HALO4;
+    if (c->halo_mode == 2 && cw.taps == 9 && cw.coutPad % 128 == 0 && H % 8 == 0) return TILE_HALO4_8x32;   // stage 4
     if (c->big_tiles && cw.coutPad % 256 == 0 && H % 16 == 0) return TILE_256x256;
     return TILE_128x128;
 }
@@ -412,7 +416,8 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
     const int rows = conv_tile_rows(tile);
     if (in.H % rows != 0 || cw.cin % kBK != 0)
         return fail(c, HCTR_ERR_ARG, "conv %s: H=%d or Cin=%d not tileable", name, in.H, cw.cin);
-    a.tilesW = (ws.W + kTileW - 1) / kTileW;
+    const int cols = conv_tile_cols(tile);
+    a.tilesW = (ws.W + cols - 1) / cols;
     a.tilesH = in.H / rows;
     a.in_sb = (int64_t)(in.H + 2) * ws.Wa * cw.cin;
     a.in_sh = ws.Wa * cw.cin;
@@ -423,7 +428,7 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
         a.out_sb = (int64_t)(outH + 2) * ws.Wa * cw.cout;
         a.out_sh = ws.Wa * cw.cout; a.out_sw = cw.cout;
         a.out_off = (int64_t)(ws.Wa + 1) * cw.cout;
-        a.out_wlimit = a.tilesW * kTileW;
+        a.out_wlimit = a.tilesW * cols;
     }
     a.relu = relu; a.pool = pool;
     a.mtiles = ws.B * a.tilesH * a.tilesW;
@@ -442,7 +447,10 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
               half_t* o, half_t* r, int planes) {
     const Workspace& ws = c->ws;
     const int H = in.H;
-    const int tilesW = (ws.W + kTileW - 1) / kTileW;
+    auto tiles_of = [&](const ConvW& cw) {
+        const ConvTile t = pick_tile(c, cw, H);
+        return (H / conv_tile_rows(t)) * ((ws.W + conv_tile_cols(t) - 1) / conv_tile_cols(t));
+    };
     const float inv_hw = 1.0f / ((float)H * (float)ws.W);
     const half_t* res = in.p;
     if (bw.has_ds) {
@@ -450,7 +458,7 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
         res = r;
     }
     if (c->fuse_se) {
-        const int tiles1 = (H / conv_tile_rows(pick_tile(c, bw.conv1, H))) * tilesW;
+        const int tiles1 = tiles_of(bw.conv1);
         TRY(run_conv(c, pf, (name + ".conv1").c_str(), bw.conv1, in, t, H, true, false, ws.se_part, false));
         pf.begin((name + ".se_border").c_str());
         HIP_TRY(c, launch_se_border(t, ws.B, H, ws.W, ws.Wa, planes, ws.se_border, c->stream));
@@ -469,7 +477,7 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
     TRY(run_conv(c, pf, (name + ".conv1").c_str(), bw.conv1, in, t, H, true, false, nullptr, false));
     TRY(run_conv(c, pf, (name + ".conv2").c_str(), bw.conv2, ActDesc{t, H, planes}, o, H, false, false,
                  ws.se_part, false));
-    const int tiles = (H / conv_tile_rows(pick_tile(c, bw.conv2, H))) * tilesW;
+    const int tiles = tiles_of(bw.conv2);
     pf.begin((name + ".se_fc").c_str());
     HIP_TRY(c, launch_se_fc(ws.se_part, tiles, bw.se.w1, bw.se.w2, ws.se_scale, ws.B, planes, inv_hw, c->stream));
     pf.end();
@@ -597,6 +605,7 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
         return fail(nullptr, HCTR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     if (const char* bt = getenv("HCTR_BIG_TILES")) c->big_tiles = atoi(bt) != 0;
+    if (const char* hm = getenv("HCTR_HALO")) c->halo_mode = atoi(hm);
     if (const char* fs = getenv("HCTR_FUSE_SE")) c->fuse_se = atoi(fs) != 0;
     if (const char* wb = getenv("HCTR_WS_BUDGET_GB")) {
         const long long v = atoll(wb);

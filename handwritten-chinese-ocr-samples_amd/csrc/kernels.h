@@ -39,9 +39,14 @@ struct ConvArgs {
 };
 
 // tile configurations: (couts x pixels) per 256-thread block
-enum ConvTile { TILE_64x256 = 0, TILE_128x128 = 1, TILE_256x256 = 2 };
-inline int conv_tile_rows(ConvTile t) { return t == TILE_128x128 ? 8 : 16; }
-inline int conv_tile_couts(ConvTile t) { return t == TILE_64x256 ? 64 : (t == TILE_128x128 ? 128 : 256); }
+// TILE_HALO4 / TILE_HALO4_8x32: 128 couts x (16x16 | 8x32) pixels, 4 waves, halo-reuse 3x3 kernel
+// (two workgroups per CU)
+enum ConvTile { TILE_64x256 = 0, TILE_128x128 = 1, TILE_256x256 = 2, TILE_HALO4 = 3, TILE_HALO4_8x32 = 4 };
+inline int conv_tile_rows(ConvTile t) { return (t == TILE_128x128 || t == TILE_HALO4_8x32) ? 8 : 16; }
+inline int conv_tile_cols(ConvTile t) { return t == TILE_HALO4_8x32 ? 32 : 16; }
+inline int conv_tile_couts(ConvTile t) {
+    return t == TILE_64x256 ? 64 : (t == TILE_256x256 ? 256 : 128);
+}
 
 hipError_t launch_conv(const ConvArgs& a, ConvTile tile, int taps, bool linear_f32, hipStream_t s);
 size_t conv_lds_bytes(ConvTile tile);

@@ -35,7 +35,8 @@ __device__ __forceinline__ void glds16_asm(const char* gsrc, char* lds_dst) {
 // -------------------------------------------------------------------------------------------
 template <int WN, int WM, int JT, bool LINEAR>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT][4], char* smem, int tid, int lane,
-                                              int wn, int wm, int n0, int mt, int img, int th, int tw) {
+                                              int wn, int wm, int n0, int mt, int img, int th, int tw, int hbase,
+                                              int w0) {
     constexpr int WC = JT * 16;
     constexpr int BN = WN * WC, BM = WM * 64;
     const int q = lane >> 4;
@@ -65,9 +66,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
         return;
     }
 
-    const int w = tw * kTileW + c;
+    const int w = w0 + c;
     const bool wvalid = w < a.W;
-    const int hbase = th * (4 * WM) + wm * 4;
     half_t* out = (half_t*)a.y;
     const int64_t pix0 = a.out_off + img * a.out_sb + (int64_t)w * a.out_sw + cw0;
 
@@ -365,7 +365,21 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
         }
     }
 
-    conv_epilogue<WN, WM, JT, LINEAR>(a, acc, smem, tid, lane, wn, wm, n0, mt, img, th, tw);
+    conv_epilogue<WN, WM, JT, LINEAR>(a, acc, smem, tid, lane, wn, wm, n0, mt, img, th, tw, th * (4 * WM) + wm * 4,
+                                      tw * kTileW);
+}
+
+// hipFuncSetAttribute is per device: remember which devices already raised a kernel's LDS limit
+// (a process may own contexts on several GPUs).
+static hipError_t raise_lds_limit(const void* fn, int bytes, bool (&done)[64]) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done[dev] = true;
+    return e;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -553,7 +567,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvArgs a) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last (redundant) DMA has landed
-    conv_epilogue<WN, WM, JT, false>(a, acc, smem, tid, lane, wn, wm, n0, mt, img, th, tw);
+    conv_epilogue<WN, WM, JT, false>(a, acc, smem, tid, lane, wn, wm, n0, mt, img, th, tw, th * 16 + wm * 4, tw * 16);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -567,8 +581,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvArgs a) {
 // -------------------------------------------------------------------------------------------
 constexpr int kHalo4Lds = 2 * 16384 + kHaloBytes;          // 78848
 
+// GEOM 0: 16 rows x 16 columns (halo 18 x 18, row stride 20); GEOM 1: 8 rows x 32 columns for the
+// H = 8 stage (halo 10 x 34, row stride 36). Both strides are 4 (mod 8) and both halos are 360 rows.
+template <int GEOM>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a) {
     constexpr int WN = 1, WM = 4, JT = 8, BN = 128;
+    constexpr int TR = GEOM ? 8 : 16, TC = GEOM ? 32 : 16;       // tile rows / columns
+    constexpr int S = TC + 4;                                      // halo row stride in pixels
+    static_assert((TR + 2) * S * 128 == kHaloBytes, "halo footprint");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -592,7 +612,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     const int cin = a.Cin;
     const int nkc = cin / kBK;
 
-    const char* xbase = (const char*)(a.x + img * a.in_sb + (int64_t)(th * 16) * a.in_sh + (int64_t)(tw * 16) * cin);
+    const char* xbase = (const char*)(a.x + img * a.in_sb + (int64_t)(th * TR) * a.in_sh + (int64_t)(tw * TC) * cin);
+    const int wrow = GEOM ? (wm >> 1) * 4 : wm * 4;               // this wave's 4 x 16 patch inside the tile
+    const int wcol = GEOM ? (wm & 1) * 16 : 0;
     const char* wbase = (const char*)(a.w + (int64_t)n0 * cin);
     uint32_t woff[4], hoff[12];
 #pragma unroll
@@ -605,9 +627,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     for (int r = 0; r < 12; ++r) {                          // piece wv + 4r
         const int g = (wv + 4 * r) * 64 + lane;
         const int row = g >> 3, cp = (g & 7) ^ (row & 7);
-        int hy = row / kHaloCols, hx = row - hy * kHaloCols;
-        if (hx > 17) hx = 17;
-        if (hy > 17) hy = 17;
+        int hy = row / S, hx = row - hy * S;
+        if (hx > TC + 1) hx = TC + 1;                       // pad columns: any valid address
+        if (hy > TR + 1) hy = TR + 1;                       // pieces >= 45 are never issued
         hoff[r] = ((uint32_t)hy * (uint32_t)a.in_sh + (uint32_t)hx * (uint32_t)cin) * 2u + cp * 16;
     }
     const int q = lane >> 4, c = lane & 15;
@@ -635,7 +657,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
 
     stage_halo(0);
     stage_weights(0, 0, 0);
-    const int hbuf = 32768 + (wm * 4) * (kHaloCols * 128);
+    const int hbuf = 32768 + wrow * (S * 128);
 
     for (int kc = 0; kc < nkc; ++kc) {
         const bool next_chunk = kc + 1 < nkc;
@@ -646,9 +668,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int tdy = tap / 3, dx = tap - tdy * 3 - 1;
-            const int u = c + 1 + dx;
+            const int u = wcol + c + 1 + dx;
             const int v0 = u * 128 + (((q ^ (u & 7) ^ ((tdy & 1) << 2)) & 7) << 4);
-            const char* hb = smem + hbuf + tdy * (kHaloCols * 128);
+            const char* hb = smem + hbuf + tdy * (S * 128);
             const char* be = hb + v0;
             const char* bo = hb + (v0 ^ 64);
             const char* wt = smem + (k & 1) * 16384;
@@ -662,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             auto read_b = [&](int ks, f16x8 (&dst)[4]) {
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
-                    dst[n] = *(const f16x8*)((((n & 1) ^ ks) ? bo : be) + n * (kHaloCols * 128));
+                    dst[n] = *(const f16x8*)((((n & 1) ^ ks) ? bo : be) + n * (S * 128));
             };
             __builtin_amdgcn_sched_barrier(0);
             read_b(0, bq[0]);
@@ -702,31 +724,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last (redundant) weight DMA has landed
-    conv_epilogue<WN, WM, JT, false>(a, acc, smem, tid, lane, 0, wm, n0, mt, img, th, tw);
+    conv_epilogue<WN, WM, JT, false>(a, acc, smem, tid, lane, 0, wm, n0, mt, img, th, tw, th * TR + wrow,
+                                     tw * TC + wcol);
 }
 
+template <int GEOM>
 static hipError_t launch_conv_halo4(const ConvArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           kHalo4Lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    ConvArgs b = a;
-    b.ntiles = a.CoutPad / 128;                             // 128-cout tiles
-    hipLaunchKernelGGL(conv3x3_halo4_kernel, dim3(b.mtiles * b.ntiles), dim3(256), kHalo4Lds, s, b);
+    static bool done[64] = {};
+    hipError_t e0 = raise_lds_limit((const void*)conv3x3_halo4_kernel<GEOM>, kHalo4Lds, done);
+    if (e0 != hipSuccess) return e0;
+    hipLaunchKernelGGL(conv3x3_halo4_kernel<GEOM>, dim3(a.mtiles * a.ntiles), dim3(256), kHalo4Lds, s, a);
     return hipGetLastError();
 }
 
 static hipError_t launch_conv_halo(const ConvArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           kHaloLds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static bool done[64] = {};
+    hipError_t e0 = raise_lds_limit((const void*)conv3x3_halo_kernel, kHaloLds, done);
+    if (e0 != hipSuccess) return e0;
     static const int dbg = [] { const char* e = getenv("HCTR_DBG"); return e ? atoi(e) : 0; }();
     ConvArgs b = a;
     b.dbg = dbg;
@@ -745,12 +759,9 @@ size_t conv_lds_bytes(ConvTile tile) {
 template <int WN, int WM, int JT, int TAPS, bool LINEAR, bool PIPE>
 static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
     auto kern = conv_mfma_kernel<WN, WM, JT, TAPS, LINEAR, PIPE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static bool done[64] = {};
+    hipError_t e0 = raise_lds_limit((const void*)kern, (int)lds, done);
+    if (e0 != hipSuccess) return e0;
     const int grid = a.mtiles * a.ntiles;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WN * WM * 64), lds, s, a);
     return hipGetLastError();
@@ -758,7 +769,8 @@ static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
 
 hipError_t launch_conv(const ConvArgs& a, ConvTile tile, int taps, bool linear_f32, hipStream_t s) {
     const size_t lds = conv_lds_bytes(tile);
-    // HCTR_HALO: 0 = generic kernel, 1 = 8-wave halo kernel, 2 = two 4-wave halo workgroups per CU
+    // HCTR_HALO (read by the engine too): 0 = generic kernels, 1 = 8-wave halo kernel on 256x256 tiles,
+    // 2 (default) = TILE_HALO4 chosen by the engine wherever a 3x3 layer allows it
     static const int halo = [] { const char* e = getenv("HCTR_HALO"); return e ? atoi(e) : 2; }();
     static const bool pipe = [] { const char* e = getenv("HCTR_PIPE"); return e ? atoi(e) != 0 : false; }();
     if (linear_f32) {
@@ -767,11 +779,14 @@ hipError_t launch_conv(const ConvArgs& a, ConvTile tile, int taps, bool linear_f
         return launch_conv_t<2, 2, 4, 1, true, false>(a, lds, s);
     }
     switch (tile) {
+        case TILE_HALO4:
+            return taps == 9 ? launch_conv_halo4<0>(a, s) : hipErrorInvalidValue;
+        case TILE_HALO4_8x32:
+            return taps == 9 ? launch_conv_halo4<1>(a, s) : hipErrorInvalidValue;
         case TILE_64x256:
             return taps == 9 ? launch_conv_t<1, 4, 4, 9, false, false>(a, lds, s)
                              : launch_conv_t<1, 4, 4, 1, false, false>(a, lds, s);
         case TILE_256x256:
-            if (taps == 9 && halo == 2) return launch_conv_halo4(a, s);
             if (taps == 9 && halo) return launch_conv_halo(a, s);
             if (taps == 9)
                 return pipe ? launch_conv_t<2, 4, 8, 9, false, true>(a, lds, s)
