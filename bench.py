@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--cpu-lines", type=int, default=2)
     ap.add_argument("--layers", action="store_true", help="print the per-layer device-time table to stderr")
     ap.add_argument("--layer-file", default="", help="write the per-step launch order (layer names) to this file")
+    ap.add_argument("--no-pipeline", action="store_true", help="c5: run front end and host search back to back")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"],
                     help="c2 (default, the driver's line): B=64 x W=2000 greedy; c3: B=512 mixed widths "
                          "{800,1600,2400,3200} bucketed; c5: B=256 x W=2000 beam search 10/10 (extra modes, 1 GPU)")
@@ -215,14 +216,20 @@ def extra_config(args, hctr_amd, model, sd, dev):
         codec.ngram = hctr_amd.ToyBigramLM()
         t_front = [0.0]
 
+        import importlib
+        pipe = importlib.import_module(hctr_amd.package.__name__ + ".pipeline")
+
         def step():
-            t0 = time.perf_counter()
-            fe = model.beam_frontend(dev_imgs, k=10)
-            t_front[0] += time.perf_counter() - t0
-            return codec.decode_frontend(fe)
+            if args.no_pipeline:
+                t0 = time.perf_counter()
+                fe = model.beam_frontend(dev_imgs, k=10)
+                t_front[0] += time.perf_counter() - t0
+                return codec.decode_frontend(fe)
+            return pipe.recognize_beam(model, codec, dev_imgs, chunk=64)
         n_lines, cols = 256, 256 * W_LINE
         name = ("BASELINE configs[4]: B=256 x 1x128x2000, cbs_full beam 10 / depth 10, toy-bigram LM, "
-                "device log-softmax+top-k, C++ host prefix search on %d threads" % len(os.sched_getaffinity(0)))
+                "device log-softmax+top-k, C++ host prefix search on %d threads, %s" %
+                (len(os.sched_getaffinity(0)), "sequential" if args.no_pipeline else "GPU front end pipelined with host search"))
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize(dev)

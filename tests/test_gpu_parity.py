@@ -400,3 +400,18 @@ def test_other_vocabulary_size_and_checkpoint_file(tmp_path, pkg, synth):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Model output classes: 102" in r.stdout
     assert ("predicted results: %r" % want) in r.stdout
+
+
+def test_pipelined_beam_equals_sequential(pkg, engine, synth):
+    """pipeline.recognize_beam (front end of chunk i+1 overlapped with the host search of chunk i)
+    returns exactly what the two stages give back to back on the same chunks."""
+    from importlib import import_module
+    pipe = import_module(pkg.__name__ + ".pipeline")
+    imgs = synth.make_line_images(5, 120, 61)
+    cd = pkg.ctc_codec(synth.characters()).attach(engine)
+    cd.use_beam_search, cd.use_tfm_pred, cd.ngram = True, False, pkg.ToyBigramLM()
+    cd.lm_panelty, cd.len_bonus = 0.8, 4.8
+    want = []
+    for lo in range(0, 5, 2):
+        want += cd.decode_frontend(engine.beam_frontend(imgs[lo:lo + 2], k=10))
+    assert pipe.recognize_beam(engine, cd, imgs, chunk=2) == want
