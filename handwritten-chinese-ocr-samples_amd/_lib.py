@@ -86,6 +86,7 @@ SIGNATURES = [
     ("hctr_version", ctypes.c_char_p, []),
     ("hctr_load_tensor", _I, [_VP, ctypes.c_char_p, _VP, c_i64p, _I, _I]),
     ("hctr_finalize_weights", _I, [_VP]),
+    ("hctr_set_precision", _I, [_VP, _I]),
     ("hctr_forward_logits", _I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I]),
     ("hctr_greedy", _I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _VP]),
     ("hctr_decode_greedy_logits", _I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP]),

@@ -100,6 +100,11 @@ struct hctr_ctx {
     int64_t max_cols = kDefaultMaxCols;
     bool big_tiles = true;
     int halo_mode = 2;
+    // f16x3 precision mode: every activation and weight is carried as hi + lo fp16 pairs; a conv sees
+    // tripled input channels [x_hi | x_lo | x_hi] against weight rows [w_hi | w_hi | w_lo], so the MFMA
+    // main loops are unchanged and the products w_hi*x_hi + w_hi*x_lo + w_lo*x_hi are summed in fp32.
+    bool split = false;
+    int chm() const { return split ? 3 : 1; }      // channel multiplier of activation buffers
     bool fuse_se = true;
     // profiling
     bool profiling = false;
@@ -201,7 +206,8 @@ int build_conv(hctr_ctx* c, const std::string& ck, const std::string& bk, int ci
     TRY(need(c, bk + ".running_var", {cout}, &var));
     const int taps = ks * ks;
     const int coutPad = (cout + pad_to - 1) / pad_to * pad_to;
-    std::vector<half_t> hw((size_t)taps * coutPad * cin, (half_t)0.f);
+    const int cinp = c->chm() * cin;               // stored row length ([w_hi | w_hi | w_lo] when split)
+    std::vector<half_t> hw((size_t)taps * coutPad * cinp, (half_t)0.f);
     std::vector<float> hb(coutPad, 0.f);
     for (int blk = 0; blk < coutPad / 64; ++blk)
         for (int s = 0; s < 64; ++s) {
@@ -211,7 +217,13 @@ int build_conv(hctr_ctx* c, const std::string& ck, const std::string& bk, int ci
             for (int t = 0; t < taps; ++t)
                 for (int ci = 0; ci < cin; ++ci) {
                     const double v = (double)w->data[((size_t)co * cin + ci) * taps + t] * sc;
-                    hw[((size_t)t * coutPad + blk * 64 + s) * cin + ci] = (half_t)(float)v;
+                    half_t* row = &hw[((size_t)t * coutPad + blk * 64 + s) * cinp];
+                    const half_t hi = (half_t)(float)v;
+                    row[ci] = hi;
+                    if (c->split) {
+                        row[cin + ci] = hi;
+                        row[2 * cin + ci] = (half_t)(float)(v - (double)(float)hi);
+                    }
                 }
         }
     for (int co = 0; co < cout; ++co) {
@@ -219,7 +231,7 @@ int build_conv(hctr_ctx* c, const std::string& ck, const std::string& bk, int ci
         const double bb = has_bias ? (double)b->data[co] : 0.0;
         hb[co] = (float)((bb - (double)mean->data[co]) * sc + (double)beta->data[co]);
     }
-    out->cin = cin; out->cout = cout; out->coutPad = coutPad; out->taps = taps;
+    out->cin = cinp; out->cout = cout; out->coutPad = coutPad; out->taps = taps;
     TRY(dev_alloc(c, c->wallocs, &out->w, hw.size(), false));
     TRY(dev_alloc(c, c->wallocs, &out->bias, hb.size(), false));
     HIP_TRY(c, hipMemcpyAsync(out->w, hw.data(), hw.size() * sizeof(half_t), hipMemcpyHostToDevice, c->stream));
@@ -271,19 +283,31 @@ int build_head(hctr_ctx* c) {
     TRY(need(c, "linear.weight", {C, kFeat}, &w));
     TRY(need(c, "linear.bias", {C}, &b));
     const int cpad = c->cpad;
-    std::vector<half_t> hw((size_t)cpad * kFeat, (half_t)0.f);
+    const int kf = c->chm() * kFeat;               // [h][hi | lo-slot | hi-slot][512] when split
+    std::vector<half_t> hw((size_t)cpad * kf, (half_t)0.f);
     std::vector<float> hb(cpad, 0.f);
     for (int blk = 0; blk < cpad / 64; ++blk)
         for (int s = 0; s < 64; ++s) {
             const int n = blk * 64 + perm64(s);
             if (n >= C) continue;
-            half_t* dst = &hw[(size_t)(blk * 64 + s) * kFeat];
+            half_t* dst = &hw[(size_t)(blk * 64 + s) * kf];
             const float* src = &w->data[(size_t)n * kFeat];
             for (int ch = 0; ch < 512; ++ch)
-                for (int h = 0; h < 4; ++h) dst[h * 512 + ch] = (half_t)src[ch * 4 + h];
+                for (int h = 0; h < 4; ++h) {
+                    const float v = src[ch * 4 + h];
+                    const half_t hi = (half_t)v;
+                    if (!c->split) {
+                        dst[h * 512 + ch] = hi;
+                    } else {                         // feature planes [x_hi | x_lo | x_hi] x [w_hi | w_hi | w_lo]
+                        half_t* r = dst + h * 1536;
+                        r[ch] = hi;
+                        r[512 + ch] = hi;
+                        r[1024 + ch] = (half_t)(v - (float)hi);
+                    }
+                }
         }
     for (int n = 0; n < C; ++n) hb[n] = b->data[n];
-    c->head.cin = kFeat; c->head.cout = C; c->head.coutPad = cpad; c->head.taps = 1;
+    c->head.cin = kf; c->head.cout = C; c->head.coutPad = cpad; c->head.taps = 1;
     TRY(dev_alloc(c, c->wallocs, &c->head.w, hw.size(), false));
     TRY(dev_alloc(c, c->wallocs, &c->head.bias, hb.size(), false));
     HIP_TRY(c, hipMemcpyAsync(c->head.w, hw.data(), hw.size() * sizeof(half_t), hipMemcpyHostToDevice, c->stream));
@@ -317,7 +341,7 @@ int ensure_workspace(hctr_ctx* c, int B, int W) {
     ws.Wa = Wa;
     const int64_t cols = (int64_t)B * W;
     // estimate, then evict least-recently-used workspaces until the new one fits the budget
-    const size_t need = (size_t)cols * 300000;
+    const size_t need = (size_t)cols * 300000 * c->chm();
     while (!c->ws_cache.empty()) {
         size_t used = 0;
         for (auto& w : c->ws_cache) used += w.bytes;
@@ -332,18 +356,19 @@ int ensure_workspace(hctr_ctx* c, int B, int W) {
     };
     A((char**)&ws.img, (size_t)cols * kImgH * 4, false);
     A(&ws.widths, (size_t)B, false);
-    A(&ws.s0, (size_t)act_elems(B, 128, Wa, 64), true);
+    const int m = c->chm();
+    A(&ws.s0, (size_t)act_elems(B, 128, Wa, 64 * m), true);
     int cin = 64;
     size_t se_max = 0;
     for (int s = 1; s <= 4; ++s) {
         const int H = kStageH[s], planes = kStagePlanes[s - 1];
-        A(&ws.x[s], (size_t)act_elems(B, H, Wa, cin), true);
+        A(&ws.x[s], (size_t)act_elems(B, H, Wa, cin * m), true);
         const int nbuf = (s == 4) ? 2 : 3;
-        for (int i = 0; i < nbuf; ++i) A(&ws.p[s][i], (size_t)act_elems(B, H, Wa, planes), true);
+        for (int i = 0; i < nbuf; ++i) A(&ws.p[s][i], (size_t)act_elems(B, H, Wa, planes * m), true);
         se_max = std::max(se_max, (size_t)B * (H / 8) * tilesW * planes);
         cin = planes;
     }
-    A(&ws.headin, (size_t)cols * kFeat, false);
+    A(&ws.headin, (size_t)cols * kFeat * m, false);
     A(&ws.logits, (size_t)cols * c->cpad, false);
     A(&ws.se_part, se_max, false);
     A(&ws.se_scale, (size_t)B * 512, false);
@@ -411,6 +436,8 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
     ConvArgs a{};
     a.x = in.p; a.w = cw.w; a.bias = cw.bias; a.y = out; a.se_part = se_part;
     a.se_scale = se_scale; a.resid = resid;
+    a.split = c->split ? 1 : 0;
+    const int m = c->chm();                        // cw.cin already counts the tripled input channels
     a.H = in.H; a.W = ws.W; a.Cin = cw.cin; a.Cout = cw.cout; a.CoutPad = cw.coutPad;
     const ConvTile tile = pick_tile(c, cw, in.H);
     const int rows = conv_tile_rows(tile);
@@ -421,13 +448,13 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
     a.tilesH = in.H / rows;
     a.in_sb = (int64_t)(in.H + 2) * ws.Wa * cw.cin;
     a.in_sh = ws.Wa * cw.cin;
-    if (to_head) {            // conv4 + pool -> head input [B][W][4][512]
-        a.out_sb = (int64_t)ws.W * kFeat; a.out_sh = 512; a.out_sw = kFeat; a.out_off = 0;
+    if (to_head) {            // conv4 + pool -> head input [B][W][4][512] (x3 planes when split)
+        a.out_sb = (int64_t)ws.W * kFeat * m; a.out_sh = 512 * m; a.out_sw = kFeat * m; a.out_off = 0;
         a.out_wlimit = ws.W;
     } else {
-        a.out_sb = (int64_t)(outH + 2) * ws.Wa * cw.cout;
-        a.out_sh = ws.Wa * cw.cout; a.out_sw = cw.cout;
-        a.out_off = (int64_t)(ws.Wa + 1) * cw.cout;
+        a.out_sb = (int64_t)(outH + 2) * ws.Wa * cw.cout * m;
+        a.out_sh = ws.Wa * cw.cout * m; a.out_sw = cw.cout * m;
+        a.out_off = (int64_t)(ws.Wa + 1) * cw.cout * m;
         a.out_wlimit = a.tilesW * cols;
     }
     a.relu = relu; a.pool = pool;
@@ -457,15 +484,15 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
         TRY(run_conv(c, pf, (name + ".downsample").c_str(), bw.ds, in, r, H, false, false, nullptr, false));
         res = r;
     }
-    if (c->fuse_se) {
+    if (c->fuse_se || c->split) {
         const int tiles1 = tiles_of(bw.conv1);
         TRY(run_conv(c, pf, (name + ".conv1").c_str(), bw.conv1, in, t, H, true, false, ws.se_part, false));
         pf.begin((name + ".se_border").c_str());
-        HIP_TRY(c, launch_se_border(t, ws.B, H, ws.W, ws.Wa, planes, ws.se_border, c->stream));
+        HIP_TRY(c, launch_se_border(t, ws.B, H, ws.W, ws.Wa, planes, c->split, ws.se_border, c->stream));
         pf.end();
         pf.begin((name + ".se_premean").c_str());
         HIP_TRY(c, launch_se_premean(ws.se_part, tiles1, ws.se_border, t, bw.conv2.w, bw.conv2.bias, ws.B, H, ws.W,
-                                     ws.Wa, planes, bw.conv2.coutPad, ws.se_mean, c->stream));
+                                     ws.Wa, planes, bw.conv2.coutPad, c->split, ws.se_mean, c->stream));
         pf.end();
         pf.begin((name + ".se_fc").c_str());
         HIP_TRY(c, launch_se_fc(ws.se_mean, 1, bw.se.w1, bw.se.w2, ws.se_scale, ws.B, planes, 1.0f, c->stream));
@@ -495,7 +522,7 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths) {
     if (c->profiling) { c->prof.clear(); c->ev_used = 0; }
     pf.begin("stem.conv0_1");
     HIP_TRY(c, launch_stem(ws.img, img_f32, have_widths ? ws.widths : nullptr, c->stem_w, c->stem_b, ws.s0, ws.B,
-                           ws.W, ws.Wa, c->stream));
+                           ws.W, ws.Wa, c->split, c->stream));
     pf.end();
     TRY(run_conv(c, pf, "conv0_2+pool", c->conv0_2, ActDesc{ws.s0, 128, 64}, ws.x[1], 64, true, true, nullptr, false));
     int cin = 64;
@@ -526,7 +553,7 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths) {
     // head GEMM
     ConvArgs a{};
     a.x = ws.headin; a.w = c->head.w; a.bias = c->head.bias; a.y = ws.logits;
-    a.Cin = kFeat; a.Cout = c->num_classes; a.CoutPad = c->cpad;
+    a.Cin = c->head.cin; a.Cout = c->num_classes; a.CoutPad = c->cpad;
     a.M = (int64_t)ws.B * ws.W; a.ldo = c->cpad;
     const ConvTile htile = (c->big_tiles && c->cpad % 256 == 0) ? TILE_256x256 : TILE_128x128;
     const int hbm = htile == TILE_256x256 ? 256 : 128;
@@ -567,7 +594,7 @@ int check_forward_args(hctr_ctx* c, const void* img, int img_dtype, int B, int W
 // lines per internal pass: at most max_cols pixel columns, balanced so every pass of a batch has the
 // same shape (one cached workspace per (B, W) instead of a second one for a short tail)
 int sub_batch(hctr_ctx* c, int B, int W) {
-    int64_t nb = c->max_cols / W;
+    int64_t nb = (c->max_cols / c->chm()) / W;
     if (nb < 1) nb = 1;
     if (nb >= B) return B;
     const int64_t passes = (B + nb - 1) / nb;
@@ -581,7 +608,9 @@ int sub_batch(hctr_ctx* c, int B, int W) {
 // =============================================================================================
 extern "C" {
 
-const char* hctr_version(void) { return "hctr-hip 0.1 (gfx950, f16 storage / f16 MFMA / f32 accumulate)"; }
+const char* hctr_version(void) {
+    return "hctr-hip 0.1 (gfx950, f16 storage / f16 MFMA / f32 accumulate; optional f16x3 split precision)";
+}
 
 int hctr_create(hctr_ctx** out, int device, int num_classes) {
     if (!out) return fail(nullptr, HCTR_ERR_ARG, "out is NULL");
@@ -606,6 +635,7 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
     }
     if (const char* bt = getenv("HCTR_BIG_TILES")) c->big_tiles = atoi(bt) != 0;
     if (const char* hm = getenv("HCTR_HALO")) c->halo_mode = atoi(hm);
+    if (const char* pr = getenv("HCTR_PRECISION")) c->split = std::string(pr) == "f16x3";
     if (const char* fs = getenv("HCTR_FUSE_SE")) c->fuse_se = atoi(fs) != 0;
     if (const char* wb = getenv("HCTR_WS_BUDGET_GB")) {
         const long long v = atoll(wb);
@@ -688,6 +718,14 @@ int hctr_finalize_weights(hctr_ctx* c) {
             return fail(c, HCTR_ERR_KEY, "Unexpected key(s) in state_dict: \"%s\"", kv.first.c_str());
     c->host.clear();
     c->finalized = true;
+    return HCTR_OK;
+}
+
+int hctr_set_precision(hctr_ctx* c, int mode) {
+    if (!c) return HCTR_ERR_ARG;
+    if (mode != 0 && mode != 1) return fail(c, HCTR_ERR_ARG, "precision mode must be 0 (f16) or 1 (f16x3)");
+    if (c->finalized) return fail(c, HCTR_ERR_STATE, "precision must be chosen before hctr_finalize_weights");
+    c->split = mode == 1;
     return HCTR_OK;
 }
 
@@ -1018,16 +1056,19 @@ int64_t hctr_debug_activation(hctr_ctx* c, const char* name, float* out, int64_t
     if (Hout) *Hout = H;
     if (!out || cap < total) return total;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const int64_t elems = head ? (int64_t)ws.B * ws.W * kFeat : act_elems(ws.B, H, ws.Wa, C);
+    const int m = c->chm();                        // [hi | lo | hi] planes in f16x3 mode: report hi + lo
+    const int64_t elems = head ? (int64_t)ws.B * ws.W * kFeat * m : act_elems(ws.B, H, ws.Wa, C * m);
     std::vector<half_t> host((size_t)elems);
     HIP_TRY(c, hipMemcpy(host.data(), p, (size_t)elems * sizeof(half_t), hipMemcpyDeviceToHost));
     for (int b = 0; b < ws.B; ++b)
         for (int ch = 0; ch < C; ++ch)
             for (int h = 0; h < H; ++h)
                 for (int w = 0; w < ws.W; ++w) {
-                    const int64_t src = head ? (((int64_t)b * ws.W + w) * 4 + h) * 512 + ch
-                                             : (((int64_t)b * (H + 2) + h + 1) * ws.Wa + w + 1) * C + ch;
-                    out[(((int64_t)b * C + ch) * H + h) * ws.W + w] = (float)host[(size_t)src];
+                    const int64_t src = head ? (((int64_t)b * ws.W + w) * 4 + h) * (512 * m) + ch
+                                             : (((int64_t)b * (H + 2) + h + 1) * ws.Wa + w + 1) * (C * m) + ch;
+                    float v = (float)host[(size_t)src];
+                    if (m == 3) v += (float)host[(size_t)src + C];
+                    out[(((int64_t)b * C + ch) * H + h) * ws.W + w] = v;
                 }
     return total;
 }

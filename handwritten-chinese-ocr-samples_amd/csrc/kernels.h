@@ -35,6 +35,8 @@ struct ConvArgs {
     int64_t M;              // linear mode: number of rows
     int64_t ldo;            // linear mode: output leading dimension (elements)
     int mtiles, ntiles;
+    int split;              // f16x3 mode: activations are [hi | lo | hi] fp16 planes of Cout channels each
+                            // (input side: Cin already counts the tripled channels)
     int dbg;                // timing experiments only (HCTR_DBG): 1 = DMA from fixed hot addresses, 2 = no DMA in the loop
 };
 
@@ -52,15 +54,16 @@ hipError_t launch_conv(const ConvArgs& a, ConvTile tile, int taps, bool linear_f
 size_t conv_lds_bytes(ConvTile tile);
 
 hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, const float* w9,
-                       const float* bias, half_t* y, int B, int W, int Wa, hipStream_t s);
+                       const float* bias, half_t* y, int B, int W, int Wa, int split, hipStream_t s);
 
 // channel sums of the border rows / columns of a padded NHWC activation: out[b][4][C] =
 // {row 0, row H-1, column 0, column W-1}
-hipError_t launch_se_border(const half_t* t, int B, int H, int W, int Wa, int C, float* out, hipStream_t s);
+hipError_t launch_se_border(const half_t* t, int B, int H, int W, int Wa, int C, int split, float* out,
+                            hipStream_t s);
 // SE mean of conv2(t) from the statistics of t (linearity of the convolution), see kernels.hip
 hipError_t launch_se_premean(const float* tsum_part, int tiles, const float* border, const half_t* t,
                              const half_t* w, const float* bias, int B, int H, int W, int Wa, int C,
-                             int CoutPad, float* mean, hipStream_t s);
+                             int CoutPad, int split, float* mean, hipStream_t s);
 
 hipError_t launch_se_fc(const float* se_part, int tiles_per_img, const float* w1, const float* w2,
                         float* scale, int B, int C, float inv_hw, hipStream_t s);

@@ -33,7 +33,7 @@ __device__ __forceinline__ void glds16_asm(const char* gsrc, char* lds_dst) {
 // lane (q, c): for cout block cb (64 couts) the lane owns couts q*16 + jj*4 + i (jj = j & 3), i.e.
 // 16 consecutive couts, of pixel column c and pixel repeat n.
 // -------------------------------------------------------------------------------------------
-template <int WN, int WM, int JT, bool LINEAR>
+template <int WN, int WM, int JT, bool LINEAR, bool SPLIT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT][4], char* smem, int tid, int lane,
                                               int wn, int wm, int n0, int mt, int img, int th, int tw, int hbase,
                                               int w0) {
@@ -72,7 +72,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
     const int64_t pix0 = a.out_off + img * a.out_sb + (int64_t)w * a.out_sw + cw0;
 
     // fused squeeze-excite + residual (BasicBlock :54-58): acc = acc * scale[img][cout] + residual
-    if (a.se_scale != nullptr) {
+    if (SPLIT && a.se_scale != nullptr) {
+        // f16x3: the residual is hi + lo (planes Cout apart); loaded per (cb, n), accuracy mode only
+        const float* sc = a.se_scale + (int64_t)img * a.Cout + cw0;
+        if (w < a.out_wlimit) {
+#pragma unroll
+            for (int cb = 0; cb < JT / 4; ++cb)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const half_t* r = a.resid + pix0 + (int64_t)(hbase + n) * a.out_sh + cb * 64;
+                    const f16x8 h0 = *(const f16x8*)r, h1 = *(const f16x8*)(r + 8);
+                    const f16x8 l0 = *(const f16x8*)(r + a.Cout), l1 = *(const f16x8*)(r + a.Cout + 8);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float rv = e < 8 ? (float)h0[e] + (float)l0[e] : (float)h1[e - 8] + (float)l1[e - 8];
+                        const float sv = sc[cb * 64 + e];
+                        acc[cb * 4 + (e >> 2)][n][e & 3] = fmaf(acc[cb * 4 + (e >> 2)][n][e & 3], sv, rv);
+                    }
+                }
+        }
+    } else if (a.se_scale != nullptr) {
         const float* sc = a.se_scale + (int64_t)img * a.Cout + cw0;
         if (w < a.out_wlimit) {
             // all residual loads first (one latency exposure), 16 couts = 2 x 16 B per (cb, n)
@@ -111,7 +130,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
                 if (a.pool && (n & 1) == 0) v = fmaxf(v, acc[j][n + 1][i]);   // (2,1) max-pool -> even n
                 if (a.relu) v = fmaxf(v, 0.f);
                 if (!wvalid) v = 0.f;
-                acc[j][n][i] = (float)(half_t)v;
+                if (SPLIT) {                        // stored as hi + lo: keep what the two planes add up to
+                    const half_t hi = (half_t)v;
+                    v = (float)hi + (float)(half_t)(v - (float)hi);
+                } else {
+                    v = (float)(half_t)v;
+                }
+                acc[j][n][i] = v;
             }
 
     if (a.se_part != nullptr) {
@@ -157,6 +182,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
                 }
                 *(f16x8*)(o + cb * 64) = lo;
                 *(f16x8*)(o + cb * 64 + 8) = hi;
+                if (SPLIT) {                        // planes: [hi | lo | hi]
+                    f16x8 l0, l1;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float v = acc[cb * 4 + (e >> 2)][n][e & 3];
+                        const half_t lv = (half_t)(v - (float)(half_t)v);
+                        if (e < 8) l0[e] = lv; else l1[e - 8] = lv;
+                    }
+                    *(f16x8*)(o + a.Cout + cb * 64) = l0;
+                    *(f16x8*)(o + a.Cout + cb * 64 + 8) = l1;
+                    *(f16x8*)(o + 2 * a.Cout + cb * 64) = lo;
+                    *(f16x8*)(o + 2 * a.Cout + cb * 64 + 8) = hi;
+                }
             }
         }
     }
@@ -184,7 +222,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
 //   applied on the global SOURCE address and again on the ds_read_b128 address (conflict-free for
 //   the 16x16x32 operand pattern; cdna guide rule 21).
 // -------------------------------------------------------------------------------------------
-template <int WN, int WM, int JT, int TAPS, bool LINEAR, bool PIPE>
+template <int WN, int WM, int JT, int TAPS, bool LINEAR, bool PIPE, bool SPLIT>
 __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int NT = WN * WM * 64;
     constexpr int WC = JT * 16;          // couts per wave (64 or 128)
@@ -365,8 +403,8 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
         }
     }
 
-    conv_epilogue<WN, WM, JT, LINEAR>(a, acc, smem, tid, lane, wn, wm, n0, mt, img, th, tw, th * (4 * WM) + wm * 4,
-                                      tw * kTileW);
+    conv_epilogue<WN, WM, JT, LINEAR, SPLIT>(a, acc, smem, tid, lane, wn, wm, n0, mt, img, th, tw,
+                                             th * (4 * WM) + wm * 4, tw * kTileW);
 }
 
 // hipFuncSetAttribute is per device: remember which devices already raised a kernel's LDS limit
@@ -567,7 +605,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvArgs a) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last (redundant) DMA has landed
-    conv_epilogue<WN, WM, JT, false>(a, acc, smem, tid, lane, wn, wm, n0, mt, img, th, tw, th * 16 + wm * 4, tw * 16);
+    conv_epilogue<WN, WM, JT, false, false>(a, acc, smem, tid, lane, wn, wm, n0, mt, img, th, tw, th * 16 + wm * 4,
+                                            tw * 16);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -583,7 +622,7 @@ constexpr int kHalo4Lds = 2 * 16384 + kHaloBytes;          // 78848
 
 // GEOM 0: 16 rows x 16 columns (halo 18 x 18, row stride 20); GEOM 1: 8 rows x 32 columns for the
 // H = 8 stage (halo 10 x 34, row stride 36). Both strides are 4 (mod 8) and both halos are 360 rows.
-template <int GEOM>
+template <int GEOM, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a) {
     constexpr int WN = 1, WM = 4, JT = 8, BN = 128;
     constexpr int TR = GEOM ? 8 : 16, TC = GEOM ? 32 : 16;       // tile rows / columns
@@ -724,17 +763,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last (redundant) weight DMA has landed
-    conv_epilogue<WN, WM, JT, false>(a, acc, smem, tid, lane, 0, wm, n0, mt, img, th, tw, th * TR + wrow,
-                                     tw * TC + wcol);
+    conv_epilogue<WN, WM, JT, false, SPLIT>(a, acc, smem, tid, lane, 0, wm, n0, mt, img, th, tw, th * TR + wrow,
+                                            tw * TC + wcol);
 }
 
+template <int GEOM, bool SPLIT>
+static hipError_t launch_conv_halo4_t(const ConvArgs& a, hipStream_t s) {
+    static bool done[64] = {};
+    hipError_t e0 = raise_lds_limit((const void*)conv3x3_halo4_kernel<GEOM, SPLIT>, kHalo4Lds, done);
+    if (e0 != hipSuccess) return e0;
+    hipLaunchKernelGGL((conv3x3_halo4_kernel<GEOM, SPLIT>), dim3(a.mtiles * a.ntiles), dim3(256), kHalo4Lds, s, a);
+    return hipGetLastError();
+}
 template <int GEOM>
 static hipError_t launch_conv_halo4(const ConvArgs& a, hipStream_t s) {
-    static bool done[64] = {};
-    hipError_t e0 = raise_lds_limit((const void*)conv3x3_halo4_kernel<GEOM>, kHalo4Lds, done);
-    if (e0 != hipSuccess) return e0;
-    hipLaunchKernelGGL(conv3x3_halo4_kernel<GEOM>, dim3(a.mtiles * a.ntiles), dim3(256), kHalo4Lds, s, a);
-    return hipGetLastError();
+    return a.split ? launch_conv_halo4_t<GEOM, true>(a, s) : launch_conv_halo4_t<GEOM, false>(a, s);
 }
 
 static hipError_t launch_conv_halo(const ConvArgs& a, hipStream_t s) {
@@ -756,15 +799,23 @@ size_t conv_lds_bytes(ConvTile tile) {
     }
 }
 
-template <int WN, int WM, int JT, int TAPS, bool LINEAR, bool PIPE>
-static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
-    auto kern = conv_mfma_kernel<WN, WM, JT, TAPS, LINEAR, PIPE>;
+template <int WN, int WM, int JT, int TAPS, bool LINEAR, bool PIPE, bool SPLIT>
+static hipError_t launch_conv_ts(const ConvArgs& a, size_t lds, hipStream_t s) {
+    auto kern = conv_mfma_kernel<WN, WM, JT, TAPS, LINEAR, PIPE, SPLIT>;
     static bool done[64] = {};
     hipError_t e0 = raise_lds_limit((const void*)kern, (int)lds, done);
     if (e0 != hipSuccess) return e0;
     const int grid = a.mtiles * a.ntiles;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WN * WM * 64), lds, s, a);
     return hipGetLastError();
+}
+template <int WN, int WM, int JT, int TAPS, bool LINEAR, bool PIPE>
+static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
+    // the split (f16x3) epilogue only exists for the fp16-output configurations the engine uses in that mode
+    if constexpr (!LINEAR && !PIPE) {
+        if (a.split) return launch_conv_ts<WN, WM, JT, TAPS, LINEAR, PIPE, true>(a, lds, s);
+    }
+    return launch_conv_ts<WN, WM, JT, TAPS, LINEAR, PIPE, false>(a, lds, s);
 }
 
 hipError_t launch_conv(const ConvArgs& a, ConvTile tile, int taps, bool linear_f32, hipStream_t s) {
@@ -808,7 +859,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ img,
                                                    const int32_t* __restrict__ widths,
                                                    const float* __restrict__ w9,
                                                    const float* __restrict__ bias,
-                                                   half_t* __restrict__ y, int B, int W, int Wa) {
+                                                   half_t* __restrict__ y, int B, int W, int Wa, int split) {
     __shared__ float sw[64 * 9];
     __shared__ float sb[64];
     for (int i = threadIdx.x; i < 64 * 9; i += 256) sw[i] = w9[i];
@@ -839,25 +890,32 @@ __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ img,
         }
         v[t] = x;
     }
-    f16x8 o;
+    f16x8 o, ol;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int co = cg * 8 + e;
         float s = sb[co];
 #pragma unroll
         for (int t = 0; t < 9; ++t) s = fmaf(sw[co * 9 + t], v[t], s);
-        o[e] = (half_t)fmaxf(s, 0.f);
+        s = fmaxf(s, 0.f);
+        o[e] = (half_t)s;
+        ol[e] = (half_t)(s - (float)o[e]);
     }
-    half_t* dst = y + (((int64_t)b * 130 + h + 1) * Wa + (w + 1)) * 64 + cg * 8;
+    const int cs = split ? 192 : 64;                 // channels per pixel ([hi | lo | hi] planes when split)
+    half_t* dst = y + (((int64_t)b * 130 + h + 1) * Wa + (w + 1)) * cs + cg * 8;
     *(f16x8*)dst = o;
+    if (split) {
+        *(f16x8*)(dst + 64) = ol;
+        *(f16x8*)(dst + 128) = o;
+    }
 }
 
 hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, const float* w9,
-                       const float* bias, half_t* y, int B, int W, int Wa, hipStream_t s) {
+                       const float* bias, half_t* y, int B, int W, int Wa, int split, hipStream_t s) {
     const int64_t npix = (int64_t)B * 128 * W;
     const int64_t grid = (npix + 31) / 32;
     hipLaunchKernelGGL(stem_kernel, dim3((unsigned)grid), dim3(256), 0, s, img, img_f32, widths_dev, w9,
-                       bias, y, B, W, Wa);
+                       bias, y, B, W, Wa, split);
     return hipGetLastError();
 }
 
@@ -874,21 +932,28 @@ hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, 
 // relu(acc * scale + residual) itself and the separate read-o/read-r/write pass disappears.
 // -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void se_border_kernel(const half_t* __restrict__ t, int H, int W, int Wa, int C,
-                                                        float* __restrict__ out) {
+                                                        int split, float* __restrict__ out) {
     __shared__ float red[256 * 8];
     const int b = blockIdx.x, job = blockIdx.y;        // 0: row 0, 1: row H-1, 2: col 0, 3: col W-1
     const int cv = C >> 3;                             // 16-byte vectors per pixel
     const int v = threadIdx.x % cv, lanes = 256 / cv, p0 = threadIdx.x / cv;
-    const half_t* img = t + (int64_t)b * (H + 2) * Wa * C;
+    const int cs = split ? 3 * C : C;                  // channels per pixel in memory
+    const half_t* img = t + (int64_t)b * (H + 2) * Wa * cs;
     const int count = job < 2 ? W : H;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (threadIdx.x < lanes * cv)
         for (int p = p0; p < count; p += lanes) {
             const int h = job == 0 ? 0 : (job == 1 ? H - 1 : p);
             const int w = job == 2 ? 0 : (job == 3 ? W - 1 : p);
-            const f16x8 x = *(const f16x8*)(img + ((int64_t)(h + 1) * Wa + (w + 1)) * C + v * 8);
+            const half_t* px = img + ((int64_t)(h + 1) * Wa + (w + 1)) * cs + v * 8;
+            const f16x8 x = *(const f16x8*)px;
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += (float)x[e];
+            if (split) {
+                const f16x8 xl = *(const f16x8*)(px + C);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)xl[e];
+            }
         }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[e];
@@ -903,8 +968,9 @@ __global__ __launch_bounds__(256) void se_border_kernel(const half_t* __restrict
     }
 }
 
-hipError_t launch_se_border(const half_t* t, int B, int H, int W, int Wa, int C, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(se_border_kernel, dim3(B, 4), dim3(256), 0, s, t, H, W, Wa, C, out);
+hipError_t launch_se_border(const half_t* t, int B, int H, int W, int Wa, int C, int split, float* out,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(se_border_kernel, dim3(B, 4), dim3(256), 0, s, t, H, W, Wa, C, split, out);
     return hipGetLastError();
 }
 
@@ -914,10 +980,12 @@ __global__ __launch_bounds__(256) void se_premean_kernel(const float* __restrict
                                                          const half_t* __restrict__ t,
                                                          const half_t* __restrict__ w,
                                                          const float* __restrict__ bias, int H, int W, int Wa,
-                                                         int C, int CoutPad, float* __restrict__ mean) {
+                                                         int C, int CoutPad, int split,
+                                                         float* __restrict__ mean) {
     __shared__ float S[9 * 512];
     const int b = blockIdx.x, cg = blockIdx.y;
-    const half_t* img = t + (int64_t)b * (H + 2) * Wa * C;
+    const int cs = split ? 3 * C : C;                  // channels per pixel / weight row length
+    const half_t* img = t + (int64_t)b * (H + 2) * Wa * cs;
     for (int ci = threadIdx.x; ci < C; ci += 256) {
         const float* p = tsum_part + (int64_t)b * tiles * C + ci;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -930,10 +998,11 @@ __global__ __launch_bounds__(256) void se_premean_kernel(const float* __restrict
         const float T = (s0 + s1) + (s2 + s3);
         const float* bd = border + (int64_t)b * 4 * C + ci;
         const float R0 = bd[0], RL = bd[C], C0 = bd[2 * C], CL = bd[3 * C];
-        const float t00 = (float)img[((int64_t)1 * Wa + 1) * C + ci];
-        const float t0L = (float)img[((int64_t)1 * Wa + W) * C + ci];
-        const float tL0 = (float)img[((int64_t)H * Wa + 1) * C + ci];
-        const float tLL = (float)img[((int64_t)H * Wa + W) * C + ci];
+        auto px = [&](int hp, int wp) {
+            const half_t* q = img + ((int64_t)hp * Wa + wp) * cs + ci;
+            return split ? (float)q[0] + (float)q[C] : (float)q[0];
+        };
+        const float t00 = px(1, 1), t0L = px(1, W), tL0 = px(H, 1), tLL = px(H, W);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
@@ -958,9 +1027,16 @@ __global__ __launch_bounds__(256) void se_premean_kernel(const float* __restrict
     const int kper = 9 * C / 4;                        // this slice's share of the 9*C reduction
     for (int kk = slice * kper; kk < (slice + 1) * kper; kk += 8) {
         const int tap = kk / C, ci = kk - tap * C;
-        const f16x8 wv8 = *(const f16x8*)(w + ((int64_t)tap * CoutPad + cg * 64 + srow) * C + ci);
+        const half_t* wr = w + ((int64_t)tap * CoutPad + cg * 64 + srow) * cs + ci;
+        const f16x8 wv8 = *(const f16x8*)wr;
+        if (split) {                                   // weight rows are [w_hi | w_hi | w_lo]
+            const f16x8 wl8 = *(const f16x8*)(wr + 2 * C);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc = fmaf((float)wv8[e], S[tap * C + ci + e], acc);
+            for (int e = 0; e < 8; ++e) acc = fmaf((float)wv8[e] + (float)wl8[e], S[tap * C + ci + e], acc);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf((float)wv8[e], S[tap * C + ci + e], acc);
+        }
     }
     __shared__ float part[256];
     part[threadIdx.x] = acc;
@@ -974,10 +1050,10 @@ __global__ __launch_bounds__(256) void se_premean_kernel(const float* __restrict
 
 hipError_t launch_se_premean(const float* tsum_part, int tiles, const float* border, const half_t* t,
                              const half_t* w, const float* bias, int B, int H, int W, int Wa, int C,
-                             int CoutPad, float* mean, hipStream_t s) {
+                             int CoutPad, int split, float* mean, hipStream_t s) {
     if (C > 512 || C % 64 != 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(se_premean_kernel, dim3(B, C / 64), dim3(256), 0, s, tsum_part, tiles, border, t, w, bias, H, W,
-                       Wa, C, CoutPad, mean);
+                       Wa, C, CoutPad, split, mean);
     return hipGetLastError();
 }
 

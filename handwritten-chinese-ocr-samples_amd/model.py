@@ -24,7 +24,12 @@ def _is_torch(x):
 
 
 class hctr_model(object):
-    def __init__(self, num_classes=7375):
+    def __init__(self, num_classes=7375, precision="f16"):
+        """``precision``: "f16" (default; fp16 storage/MFMA, fp32 accumulate) or "f16x3" (hi+lo split
+        pairs, ~3x the work, fp32-grade logits) - an engine option, not part of the reference surface."""
+        if precision not in ("f16", "f16x3"):
+            raise ValueError("precision must be 'f16' or 'f16x3'")
+        self.precision = precision
         # attributes of the reference class (models/handwritten_ctr_model.py:159-164)
         self.img_height = 128
         self.PAD = 'NormalizePAD'
@@ -65,6 +70,7 @@ class hctr_model(object):
         lib = _lib.load()
         ctx = ctypes.c_void_p()
         _lib.check(lib.hctr_create(ctypes.byref(ctx), device, int(self.noutput)))
+        _lib.check(lib.hctr_set_precision(ctx, 1 if self.precision == "f16x3" else 0), ctx)
         self._ctx, self._device = ctx, device
         if self._pending_sd is not None:
             sd, self._pending_sd = self._pending_sd, None

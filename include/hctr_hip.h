@@ -60,6 +60,14 @@ int hctr_load_tensor(hctr_ctx* ctx, const char* key, const void* host_ptr,
                      const int64_t* shape, int ndim, int dtype);
 int hctr_finalize_weights(hctr_ctx* ctx);
 
+/* ---- precision mode (call before hctr_finalize_weights) ------------------------------------------
+ * 0 = f16 (default): fp16 storage and MFMA inputs, fp32 accumulation - the 10-bit mantissa of the TF32
+ *     mode the reference enables on its GPUs (main.py:37-41).
+ * 1 = f16x3: every activation and weight is carried as a hi + lo fp16 pair and each product is formed
+ *     as w_hi*x_hi + w_hi*x_lo + w_lo*x_hi in fp32 (about 3x the matrix work and memory); logits then
+ *     agree with the fp32 CPU reference to ~1e-4 relative, for parity triage and near-tie-free decoding. */
+int hctr_set_precision(hctr_ctx* ctx, int mode);
+
 /* ---- forward: replaces hctr_model.forward --------------------------------------------------
  * models/handwritten_ctr_model.py:171-178 (trunk :115-153). Input: a batch of B line images of
  * height 128 and common width W, either HCTR_F32 [B][1][128][W] already normalised to [-1,1]

@@ -415,3 +415,62 @@ def test_pipelined_beam_equals_sequential(pkg, engine, synth):
     for lo in range(0, 5, 2):
         want += cd.decode_frontend(engine.beam_frontend(imgs[lo:lo + 2], k=10))
     assert pipe.recognize_beam(engine, cd, imgs, chunk=2) == want
+
+
+@pytest.fixture(scope="module")
+def engine_x3(pkg, synth, state_dict):
+    m = pkg.hctr_model(synth.DEFAULT_VOCAB + 2, precision="f16x3").cuda(0)
+    m.load_state_dict(state_dict)
+    return m
+
+
+X3_RTOL = 2e-4          # f16x3 logits vs the fp32 CPU reference: |err| <= X3_RTOL * max|logit|
+
+
+@pytest.mark.parametrize("name,seed,widths", [("b3w67u", 22, [67, 50, 33]), ("b2w96", 23, [96, 96])])
+def test_f16x3_mode_matches_reference_closely(engine_x3, pkg, synth, name, seed, widths):
+    """Split-precision mode (hi+lo fp16 pairs, three MFMA products per term) against the REAL reference's
+    fixtures: logits to 2e-4 of the logit scale, argmax identical wherever the reference's own top-2 margin
+    exceeds twice that, decoded text exact when the line has no such near-tie."""
+    g = np.load(os.path.join(GOLDEN, "model_small.npz"))
+    with open(os.path.join(GOLDEN, "model_strings.json")) as f:
+        strings = json.load(f)
+    imgs = synth.make_line_images(len(widths), max(widths), seed)
+    got = engine_x3(imgs, widths=widths)
+    sub = g["sub_classes"]
+    ref_sub = g[name + "/logits_sub"]
+    scale = float(np.abs(ref_sub).max())
+    err = float(np.abs(got[:, :, sub] - ref_sub).max())
+    assert err <= X3_RTOL * scale, (err, scale)
+    assert float(np.abs(got.max(axis=2) - g[name + "/max"]).max()) <= X3_RTOL * scale
+    margin = g[name + "/top10_val"][:, :, 0] - g[name + "/top10_val"][:, :, 1]
+    safe = margin > 2 * X3_RTOL * scale
+    ref_arg = g[name + "/argmax"].astype(np.int64)
+    assert safe.mean() >= 0.98
+    assert np.array_equal(got.argmax(axis=2)[safe], ref_arg[safe])
+    cd = pkg.ctc_codec(synth.characters()).attach(engine_x3)
+    text = cd.labels_to_text(engine_x3.greedy(imgs, widths=widths))
+    for b in range(len(widths)):
+        if safe[:, b].all():
+            assert text[b] == strings[name]["greedy"][b]
+    for tap in ("stage0", "stage2", "stage4"):
+        a = engine_x3.debug_activation(tap, len(widths))[:, :8, :, :16]
+        r = g[name + "/act/" + tap]
+        assert np.abs(a - r).max() <= X3_RTOL * max(1.0, np.abs(r).max()), tap
+
+
+def test_f16x3_long_line_text(engine_x3, pkg, synth):
+    """W = 2000 (config-2 width): in f16x3 mode the greedy text is within a few edits of the fp32 CPU
+    reference's (tests/golden/model_strings.json), vs ~2.5 % CER in the default f16 mode."""
+    g = np.load(os.path.join(GOLDEN, "model_lines.npz"))
+    with open(os.path.join(GOLDEN, "model_strings.json")) as f:
+        strings = json.load(f)
+    imgs = synth.make_line_images(1, 2000, 32)
+    got = engine_x3(imgs)
+    scale = float(np.abs(g["w2000/max"]).max())
+    assert float(np.abs(got.max(axis=2) - g["w2000/max"]).max()) <= X3_RTOL * scale
+    agree = (got.argmax(axis=2) == g["w2000/argmax"].astype(np.int64)).mean()
+    assert agree >= 0.999
+    cd = pkg.ctc_codec(synth.characters()).attach(engine_x3)
+    text = cd.labels_to_text(engine_x3.greedy(imgs))[0]
+    assert ctc_ref.edit_distance(text, strings["w2000"]["greedy"][0]) <= 3
