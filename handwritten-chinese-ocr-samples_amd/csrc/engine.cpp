@@ -62,7 +62,7 @@ struct Workspace {
     float* logits = nullptr;        // [B*W][Cpad]
     float* se_part = nullptr;
     float* se_scale = nullptr;
-    float* se_border = nullptr;     // [B][4][512]
+    float* se_border = nullptr;     // [B][4][8 segments][512]
     float* se_mean = nullptr;       // [B][512]
     int32_t* colidx = nullptr;      // [B*W]
     int32_t* labels = nullptr;      // [B][W]
@@ -372,7 +372,7 @@ int ensure_workspace(hctr_ctx* c, int B, int W) {
     A(&ws.logits, (size_t)cols * c->cpad, false);
     A(&ws.se_part, se_max, false);
     A(&ws.se_scale, (size_t)B * 512, false);
-    A(&ws.se_border, (size_t)B * 4 * 512, false);
+    A(&ws.se_border, (size_t)B * 4 * 8 * 512, false);
     A(&ws.se_mean, (size_t)B * 512, false);
     A(&ws.colidx, (size_t)cols, false);
     A(&ws.labels, (size_t)cols, false);

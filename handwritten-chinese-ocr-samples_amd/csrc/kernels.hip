@@ -855,67 +855,74 @@ hipError_t launch_conv(const ConvArgs& a, ConvTile tile, int taps, bool linear_f
 // and models/handwritten_ctr_model.py:116-118. Memory-bound: 1 B in, 128 B out per pixel.
 // One thread = one pixel x 8 output channels (one 16-byte store).
 // -------------------------------------------------------------------------------------------
+constexpr int kStemRows = 16;       // rows per thread (sliding 3x3 window in registers)
+
 __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ img, int img_f32,
                                                    const int32_t* __restrict__ widths,
                                                    const float* __restrict__ w9,
                                                    const float* __restrict__ bias,
                                                    half_t* __restrict__ y, int B, int W, int Wa, int split) {
-    __shared__ float sw[64 * 9];
-    __shared__ float sb[64];
-    for (int i = threadIdx.x; i < 64 * 9; i += 256) sw[i] = w9[i];
-    if (threadIdx.x < 64) sb[threadIdx.x] = bias[threadIdx.x];
-    __syncthreads();
-    const int cg = threadIdx.x & 7;                 // channel group of 8
-    const int64_t pix = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
-    const int64_t npix = (int64_t)B * 128 * W;
-    if (pix >= npix) return;
-    const int w = (int)(pix % W);
-    const int h = (int)((pix / W) % 128);
-    const int b = (int)(pix / ((int64_t)W * 128));
-    const int wlim = widths ? widths[b] : W;
-    float v[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
-        float x = 0.f;                                // conv zero padding (in normalised space)
-        if (hh >= 0 && hh < 128 && ww >= 0 && ww < W) {
-            const int wsrc = ww < wlim ? ww : wlim - 1;   // replicate pad
-            const int64_t off = ((int64_t)b * 128 + hh) * W + wsrc;
-            if (img_f32) {
-                x = ((const float*)img)[off];
-            } else {
-                x = (float)((const uint8_t*)img)[off] / 255.0f;
-                x = (x - 0.5f) / 0.5f;
-            }
-        }
-        v[t] = x;
-    }
-    f16x8 o, ol;
+    // thread = (8-channel group, image column); it walks kStemRows rows keeping the 3x3 window and its
+    // 72 weights in registers: 3 new pixels and one 16-byte store per output pixel.
+    const int cg = threadIdx.x & 7;
+    const int w = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int h0 = blockIdx.y * kStemRows;
+    const int b = blockIdx.z;
+    if (w >= W) return;
+    float wt[8][9], bs[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int co = cg * 8 + e;
-        float s = sb[co];
+        bs[e] = bias[cg * 8 + e];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) s = fmaf(sw[co * 9 + t], v[t], s);
-        s = fmaxf(s, 0.f);
-        o[e] = (half_t)s;
-        ol[e] = (half_t)(s - (float)o[e]);
+        for (int t = 0; t < 9; ++t) wt[e][t] = w9[(cg * 8 + e) * 9 + t];
     }
+    const int wlim = widths ? widths[b] : W;
+    auto pixel = [&](int hh, int ww) -> float {
+        if (hh < 0 || hh >= 128 || ww < 0 || ww >= W) return 0.f;       // conv zero padding (normalised space)
+        const int wsrc = ww < wlim ? ww : wlim - 1;                       // NormalizePAD replicate pad
+        const int64_t off = ((int64_t)b * 128 + hh) * W + wsrc;
+        if (img_f32) return ((const float*)img)[off];
+        float x = (float)((const uint8_t*)img)[off] / 255.0f;
+        return (x - 0.5f) / 0.5f;
+    };
+    float win[3][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) win[r + 1][d] = pixel(h0 - 1 + r, w - 1 + d);
     const int cs = split ? 192 : 64;                 // channels per pixel ([hi | lo | hi] planes when split)
-    half_t* dst = y + (((int64_t)b * 130 + h + 1) * Wa + (w + 1)) * cs + cg * 8;
-    *(f16x8*)dst = o;
-    if (split) {
-        *(f16x8*)(dst + 64) = ol;
-        *(f16x8*)(dst + 128) = o;
+    for (int r = 0; r < kStemRows; ++r) {
+        const int h = h0 + r;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            win[0][d] = win[1][d];
+            win[1][d] = win[2][d];
+            win[2][d] = pixel(h + 1, w - 1 + d);
+        }
+        f16x8 o, ol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float sv = bs[e];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) sv = fmaf(wt[e][t], win[t / 3][t % 3], sv);
+            sv = fmaxf(sv, 0.f);
+            o[e] = (half_t)sv;
+            ol[e] = (half_t)(sv - (float)o[e]);
+        }
+        half_t* dst = y + (((int64_t)b * 130 + h + 1) * Wa + (w + 1)) * cs + cg * 8;
+        *(f16x8*)dst = o;
+        if (split) {
+            *(f16x8*)(dst + 64) = ol;
+            *(f16x8*)(dst + 128) = o;
+        }
     }
 }
 
 hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, const float* w9,
                        const float* bias, half_t* y, int B, int W, int Wa, int split, hipStream_t s) {
-    const int64_t npix = (int64_t)B * 128 * W;
-    const int64_t grid = (npix + 31) / 32;
-    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)grid), dim3(256), 0, s, img, img_f32, widths_dev, w9,
-                       bias, y, B, W, Wa, split);
+    if (B == 0) return hipSuccess;
+    hipLaunchKernelGGL(stem_kernel, dim3((W + 31) / 32, 128 / kStemRows, B), dim3(256), 0, s, img, img_f32, widths_dev,
+                       w9, bias, y, B, W, Wa, split);
     return hipGetLastError();
 }
 
@@ -931,18 +938,23 @@ hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, 
 // below and four direct reads. The scale is then known BEFORE conv2 runs, so conv2's epilogue applies
 // relu(acc * scale + residual) itself and the separate read-o/read-r/write pass disappears.
 // -------------------------------------------------------------------------------------------
+constexpr int kBorderSeg = 8;       // each border line is summed by 8 blocks (partials reduced in se_premean)
+
 __global__ __launch_bounds__(256) void se_border_kernel(const half_t* __restrict__ t, int H, int W, int Wa, int C,
                                                         int split, float* __restrict__ out) {
     __shared__ float red[256 * 8];
     const int b = blockIdx.x, job = blockIdx.y;        // 0: row 0, 1: row H-1, 2: col 0, 3: col W-1
+    const int seg = blockIdx.z;
     const int cv = C >> 3;                             // 16-byte vectors per pixel
     const int v = threadIdx.x % cv, lanes = 256 / cv, p0 = threadIdx.x / cv;
     const int cs = split ? 3 * C : C;                  // channels per pixel in memory
     const half_t* img = t + (int64_t)b * (H + 2) * Wa * cs;
     const int count = job < 2 ? W : H;
+    const int per = (count + kBorderSeg - 1) / kBorderSeg;
+    const int pbeg = seg * per, pend = pbeg + per < count ? pbeg + per : count;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (threadIdx.x < lanes * cv)
-        for (int p = p0; p < count; p += lanes) {
+        for (int p = pbeg + p0; p < pend; p += lanes) {
             const int h = job == 0 ? 0 : (job == 1 ? H - 1 : p);
             const int w = job == 2 ? 0 : (job == 3 ? W - 1 : p);
             const half_t* px = img + ((int64_t)(h + 1) * Wa + (w + 1)) * cs + v * 8;
@@ -964,13 +976,14 @@ __global__ __launch_bounds__(256) void se_border_kernel(const half_t* __restrict
 #pragma unroll
             for (int e = 0; e < 8; ++e) s[e] += red[(l * cv + threadIdx.x) * 8 + e];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) out[((int64_t)b * 4 + job) * C + threadIdx.x * 8 + e] = s[e];
+        for (int e = 0; e < 8; ++e)
+            out[(((int64_t)b * 4 + job) * kBorderSeg + seg) * C + threadIdx.x * 8 + e] = s[e];
     }
 }
 
 hipError_t launch_se_border(const half_t* t, int B, int H, int W, int Wa, int C, int split, float* out,
                             hipStream_t s) {
-    hipLaunchKernelGGL(se_border_kernel, dim3(B, 4), dim3(256), 0, s, t, H, W, Wa, C, split, out);
+    hipLaunchKernelGGL(se_border_kernel, dim3(B, 4, kBorderSeg), dim3(256), 0, s, t, H, W, Wa, C, split, out);
     return hipGetLastError();
 }
 
@@ -996,8 +1009,16 @@ __global__ __launch_bounds__(256) void se_premean_kernel(const float* __restrict
         }
         for (; i < tiles; ++i) s0 += p[(int64_t)i * C];
         const float T = (s0 + s1) + (s2 + s3);
-        const float* bd = border + (int64_t)b * 4 * C + ci;
-        const float R0 = bd[0], RL = bd[C], C0 = bd[2 * C], CL = bd[3 * C];
+        float bsum[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {               // fixed-order sum of the segment partials
+            const float* bd = border + (((int64_t)b * 4 + jb) * kBorderSeg) * C + ci;
+            float sv = 0.f;
+#pragma unroll
+            for (int sg = 0; sg < kBorderSeg; ++sg) sv += bd[(int64_t)sg * C];
+            bsum[jb] = sv;
+        }
+        const float R0 = bsum[0], RL = bsum[1], C0 = bsum[2], CL = bsum[3];
         auto px = [&](int hp, int wp) {
             const half_t* q = img + ((int64_t)hp * Wa + wp) * cs + ci;
             return split ? (float)q[0] + (float)q[C] : (float)q[0];
