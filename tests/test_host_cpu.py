@@ -279,3 +279,38 @@ def test_beam_search_with_native_arpa_lm(pkg, tmp_path):
     cd = pkg.ctc_codec(chars)
     cd.set_beam_search(ngram_path=toy, use_tfm_pred=False, lm_panelty=0.8, len_bonus=4.8)   # -kp file.arpa
     assert isinstance(cd.ngram, pkg.ArpaLM)
+
+
+def test_host_beam_search_fuzz(pkg):
+    """Property test (hypothesis): for random shapes, logits styles and beam settings the C++ search
+    returns exactly the oracle codec's strings (or raises IndexError exactly when the oracle does)."""
+    from hypothesis import given, settings, strategies as st
+    from oracle import ctc_ref
+
+    @settings(max_examples=40, deadline=None)
+    @given(seed=st.integers(0, 10 ** 6), w=st.integers(1, 40), b=st.integers(1, 3), c=st.integers(3, 40),
+           style=st.sampled_from(["peaky", "flat", "mixed"]), skip=st.booleans(),
+           lm=st.sampled_from(["zero", "toy"]), beam=st.integers(1, 12), depth=st.integers(1, 12),
+           lp=st.floats(0.0, 3.0), lb=st.floats(0.0, 8.0))
+    def run(seed, w, b, c, style, skip, lm, beam, depth, lp, lb):
+        logits = codec_cases.gen_logits(seed, w, b, c, style)
+        chars = codec_cases.vocab(c)
+        oc = ctc_ref.CtcCodecRef(chars)
+        oc.use_beam_search, oc.use_tfm_pred, oc.skip_search = True, False, skip
+        oc.beam_size, oc.search_depth, oc.lm_panelty, oc.len_bonus = beam, depth, lp, lb
+        oc.ngram = ctc_ref.ZeroLM() if lm == "zero" else ctc_ref.ToyBigramLM()
+        try:
+            want = oc.decode(logits)
+        except IndexError:
+            want = "IndexError"
+        cd = pkg.ctc_codec(chars)
+        cd.use_beam_search, cd.use_tfm_pred, cd.skip_search = True, False, skip
+        cd.beam_size, cd.search_depth, cd.lm_panelty, cd.len_bonus = beam, depth, lp, lb
+        cd.ngram = pkg.ZeroLM() if lm == "zero" else pkg.ToyBigramLM()
+        try:
+            got = cd.decode_frontend(_frontend_numpy(logits, min(depth, c)))
+        except IndexError:
+            got = "IndexError"
+        assert got == want
+
+    run()
