@@ -101,9 +101,10 @@ class ctc_codec(object):
         self.skip_search = False
         self.use_beam_search = False
 
-        self.num_threads = 0          # host beam-search threads (0 = all cores); built-in LMs only
+        self.num_threads = 0          # host beam-search threads (0 = all cores, max 64); built-in LMs only
         self._ctx = None
         self._own_ctx = False
+        self._model = None            # attach(): resolve the engine context through the model at call time
         self._device = 0
 
     # -- engine binding -----------------------------------------------------------------------
@@ -114,15 +115,20 @@ class ctc_codec(object):
         return self
 
     def attach(self, model):
-        """Share an hctr_model's engine context (saves a second context on the same GPU)."""
+        """Share an hctr_model's engine context (saves a second context on the same GPU). The context is
+        looked up through the model on every call, so moving or releasing the model never leaves a
+        dangling pointer here."""
         self._drop_ctx()
-        self._ctx = model._require_ctx() if model._loaded else model._ctx
-        if self._ctx is None:
+        if model._ctx is None:
             raise RuntimeError("model is not on a GPU")
-        self._own_ctx = False
+        self._model = model
         return self
 
     def _context(self):
+        if self._model is not None:
+            if self._model._ctx is None:
+                raise RuntimeError("the attached hctr_model is no longer on a GPU")
+            return self._model._ctx
         if self._ctx is None:
             ctx = ctypes.c_void_p()
             _lib.check(_lib.load().hctr_create(ctypes.byref(ctx), self._device, max(3, len(self.characters))))
@@ -132,7 +138,7 @@ class ctc_codec(object):
     def _drop_ctx(self):
         if self._ctx is not None and self._own_ctx:
             _lib.load().hctr_destroy(self._ctx)
-        self._ctx, self._own_ctx = None, False
+        self._ctx, self._own_ctx, self._model = None, False, None
 
     def __del__(self):
         try:
@@ -214,7 +220,7 @@ class ctc_codec(object):
         params.search_depth = min(int(self.search_depth), k)
         params.lm_panelty = float(self.lm_panelty)
         params.len_bonus = float(self.len_bonus)
-        params.num_threads = int(self.num_threads) or (len(__import__("os").sched_getaffinity(0)))
+        params.num_threads = int(self.num_threads) or min(64, len(__import__("os").sched_getaffinity(0)))
         params.user = None
         chars = self.characters
         err = []

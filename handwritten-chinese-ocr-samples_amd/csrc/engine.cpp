@@ -448,6 +448,9 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
     a.tilesH = in.H / rows;
     a.in_sb = (int64_t)(in.H + 2) * ws.Wa * cw.cin;
     a.in_sh = ws.Wa * cw.cin;
+    if (a.in_sb * 2 >= ((int64_t)1 << 32) || (int64_t)(outH + 2) * ws.Wa * cw.cout * m * 2 >= ((int64_t)1 << 32))
+        return fail(c, HCTR_ERR_ARG, "line width %d too large: one image's activation exceeds the kernels' 32-bit "
+                    "in-image byte offsets (conv %s)", ws.W, name);
     if (to_head) {            // conv4 + pool -> head input [B][W][4][512] (x3 planes when split)
         a.out_sb = (int64_t)ws.W * kFeat * m; a.out_sh = 512 * m; a.out_sw = kFeat * m; a.out_off = 0;
         a.out_wlimit = ws.W;

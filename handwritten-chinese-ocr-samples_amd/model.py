@@ -40,6 +40,7 @@ class hctr_model(object):
         self._ctx = None
         self._device = None
         self._pending_sd = None
+        self._sd_host = None           # host copy of the loaded checkpoint (device moves, like nn.Module.cuda)
         self._loaded = False
 
     # -- nn.Module surface used by test.py ------------------------------------------------
@@ -54,6 +55,8 @@ class hctr_model(object):
 
     def cpu(self):
         # test.py:146-148. The engine is GPU-only; a later forward raises instead of falling back.
+        if self._loaded:
+            self._pending_sd = self._sd_host            # a later .cuda() brings the weights back
         self._release()
         self._device = None
         return self
@@ -66,6 +69,8 @@ class hctr_model(object):
         device = int(device)
         if self._ctx is not None and self._device == device:
             return self
+        if self._loaded and self._pending_sd is None:
+            self._pending_sd = self._sd_host            # moving a loaded model: re-ingest on the new device
         self._release()
         lib = _lib.load()
         ctx = ctypes.c_void_p()
@@ -116,6 +121,7 @@ class hctr_model(object):
             _lib.check(lib.hctr_load_tensor(self._ctx, k.encode("utf-8"), _lib.ptr(a), shape, a.ndim, dt), self._ctx)
         _lib.check(lib.hctr_finalize_weights(self._ctx), self._ctx)
         self._loaded = True
+        self._sd_host = sd
 
     def state_dict(self):
         raise NotImplementedError("weights live in kernel layouts on the device; keep the checkpoint dict")

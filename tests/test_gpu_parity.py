@@ -474,3 +474,21 @@ def test_f16x3_long_line_text(engine_x3, pkg, synth):
     cd = pkg.ctc_codec(synth.characters()).attach(engine_x3)
     text = cd.labels_to_text(engine_x3.greedy(imgs))[0]
     assert ctc_ref.edit_distance(text, strings["w2000"]["greedy"][0]) <= 3
+
+
+def test_model_moves_and_attached_codec(pkg, synth, state_dict):
+    """nn.Module-like device moves keep the weights; an attached codec follows the model's context."""
+    m = pkg.hctr_model(synth.DEFAULT_VOCAB + 2).cuda(0)
+    m.load_state_dict(state_dict)
+    cd = pkg.ctc_codec(synth.characters()).attach(m)
+    imgs = synth.make_line_images(1, 48, 71)
+    a = m(imgs)
+    txt = cd.decode(a)
+    m.cpu()
+    with pytest.raises(RuntimeError):
+        m(imgs)
+    with pytest.raises(RuntimeError):
+        cd.decode(a)                       # attached model is off the GPU: no dangling context
+    m.cuda(0)                              # weights come back without another load_state_dict
+    assert np.array_equal(m(imgs), a)
+    assert cd.decode(a) == txt
