@@ -209,6 +209,7 @@ int build_conv(hctr_ctx* c, const std::string& ck, const std::string& bk, int ci
     const int cinp = c->chm() * cin;               // stored row length ([w_hi | w_hi | w_lo] when split)
     std::vector<half_t> hw((size_t)taps * coutPad * cinp, (half_t)0.f);
     std::vector<float> hb(coutPad, 0.f);
+    double wmax = 0.0;
     for (int blk = 0; blk < coutPad / 64; ++blk)
         for (int s = 0; s < 64; ++s) {
             const int co = blk * 64 + perm64(s);
@@ -217,6 +218,7 @@ int build_conv(hctr_ctx* c, const std::string& ck, const std::string& bk, int ci
             for (int t = 0; t < taps; ++t)
                 for (int ci = 0; ci < cin; ++ci) {
                     const double v = (double)w->data[((size_t)co * cin + ci) * taps + t] * sc;
+                    wmax = std::max(wmax, std::fabs(v));
                     half_t* row = &hw[((size_t)t * coutPad + blk * 64 + s) * cinp];
                     const half_t hi = (half_t)(float)v;
                     row[ci] = hi;
@@ -231,6 +233,8 @@ int build_conv(hctr_ctx* c, const std::string& ck, const std::string& bk, int ci
         const double bb = has_bias ? (double)b->data[co] : 0.0;
         hb[co] = (float)((bb - (double)mean->data[co]) * sc + (double)beta->data[co]);
     }
+    if (!(wmax < 65000.0))      // also catches NaN; fp16 storage cannot hold it (degenerate running_var?)
+        return fail(c, HCTR_ERR_ARG, "%s: BatchNorm-folded weight magnitude %.3g does not fit fp16", ck.c_str(), wmax);
     out->cin = cinp; out->cout = cout; out->coutPad = coutPad; out->taps = taps;
     TRY(dev_alloc(c, c->wallocs, &out->w, hw.size(), false));
     TRY(dev_alloc(c, c->wallocs, &out->bias, hb.size(), false));
