@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (next_chunk) {
+        if (next_chunk && !(a.dbg & 32)) {              // dbg 32: timing experiment without the reload
             // single halo buffer: every wave has consumed its last B fragments of this chunk (they fed the
             // MFMAs above), so after this barrier the buffer may be overwritten with the next chunk.
             __builtin_amdgcn_s_barrier();
@@ -768,10 +768,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
 }
 
 template <int GEOM, bool SPLIT>
-static hipError_t launch_conv_halo4_t(const ConvArgs& a, hipStream_t s) {
+static hipError_t launch_conv_halo4_t(const ConvArgs& a0, hipStream_t s) {
     static bool done[64] = {};
     hipError_t e0 = raise_lds_limit((const void*)conv3x3_halo4_kernel<GEOM, SPLIT>, kHalo4Lds, done);
     if (e0 != hipSuccess) return e0;
+    static const int dbg = [] { const char* e = getenv("HCTR_DBG"); return e ? atoi(e) : 0; }();
+    ConvArgs a = a0;
+    a.dbg = dbg;
     hipLaunchKernelGGL((conv3x3_halo4_kernel<GEOM, SPLIT>), dim3(a.mtiles * a.ntiles), dim3(256), kHalo4Lds, s, a);
     return hipGetLastError();
 }

@@ -492,3 +492,27 @@ def test_model_moves_and_attached_codec(pkg, synth, state_dict):
     m.cuda(0)                              # weights come back without another load_state_dict
     assert np.array_equal(m(imgs), a)
     assert cd.decode(a) == txt
+
+
+def test_full_size_config2_properties(engine, codec, synth):
+    """BASELINE config 2 at full size (B=64 x 1x128x2000, one 33 GB pass): properties that need no oracle.
+    Lines are independent (eval-mode BN, per-image SE), so a line's labels do not depend on its batch;
+    the forward is deterministic (no float atomics); fused greedy == argmax+collapse of the logits."""
+    B, W = 64, 2000
+    imgs = synth.make_line_images(B, W, 2)
+    labels = engine.greedy(imgs)
+    again = engine.greedy(imgs)
+    assert all(np.array_equal(a, b) for a, b in zip(labels, again))               # determinism
+    assert all(0 < len(l) <= W for l in labels)
+    unk = synth.DEFAULT_VOCAB + 1
+    for lab in labels[:8]:
+        assert lab.min() >= 1 and lab.max() < unk                                  # never blank / <unknown>
+    for i in (0, 17, 63):                                                          # batch invariance
+        alone = engine.greedy(imgs[i:i + 1])[0]
+        assert np.array_equal(alone, labels[i]), i
+    pair = engine.greedy(imgs[[5, 40]])
+    assert np.array_equal(pair[0], labels[5]) and np.array_equal(pair[1], labels[40])
+    sub = imgs[:4]
+    logits = engine(sub)                                                           # [2000, 4, 7358]
+    assert codec.decode(logits) == codec.labels_to_text(labels[:4])               # fused == decode(logits)
+    assert np.isfinite(logits).all()
