@@ -9,9 +9,9 @@ Public surface = the reference's surface for this path:
   ctc_codec    drop-in for utils/ctc_codec.py:14                (engine-backed)
 plus ``synth`` (deterministic synthetic checkpoints / line images) and ``build`` / ``load_library``.
 """
-from . import synth  # noqa: F401
+from . import preprocess, synth  # noqa: F401
 from ._lib import build, load as load_library  # noqa: F401
 from .codec import ArpaLM, ToyBigramLM, ZeroLM, ctc_codec  # noqa: F401
 from .model import hctr_model  # noqa: F401
 
-__all__ = ["hctr_model", "ctc_codec", "ZeroLM", "ToyBigramLM", "ArpaLM", "synth", "build", "load_library"]
+__all__ = ["hctr_model", "ctc_codec", "ZeroLM", "ToyBigramLM", "ArpaLM", "synth", "preprocess", "build", "load_library"]

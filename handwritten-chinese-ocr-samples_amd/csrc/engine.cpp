@@ -5,6 +5,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1030,6 +1031,70 @@ int hctr_log_softmax(hctr_ctx* c, const float* logits_wbc, int on_device, int W,
         hipError_t e = launch_log_softmax_rows(dev, rows, C, y, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(out_host, y, (size_t)rows * C * 4, hipMemcpyDeviceToHost, c->stream);
         if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "log_softmax: %s", hipGetErrorString(e));
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
+    free_pool(tmp);
+    return rc;
+}
+
+int hctr_resize_lines(hctr_ctx* c, const uint8_t* packed_src, int64_t packed_bytes, const int64_t* offsets,
+                      const int32_t* heights, const int32_t* widths, const int32_t* channels, int n, int out_height,
+                      const int32_t* out_widths, int out_W, uint8_t* out, int out_on_device) {
+    if (!c) return HCTR_ERR_ARG;
+    if (n < 0 || out_height < 1 || out_W < 0 || packed_bytes < 0) return fail(c, HCTR_ERR_ARG, "bad shape");
+    if (n == 0 || out_W == 0) return HCTR_OK;
+    if (!packed_src || !offsets || !heights || !widths || !channels || !out_widths || !out)
+        return fail(c, HCTR_ERR_ARG, "NULL pointer");
+    if (n > 65535) return fail(c, HCTR_ERR_ARG, "at most 65535 images per call");
+    std::vector<ResizeLine> lines((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const int ch = channels[i];
+        if (ch != 1 && ch != 3 && ch != -3) return fail(c, HCTR_ERR_ARG, "image %d: channels must be 1, 3 (BGR) or -3 (RGB)", i);
+        if (heights[i] < 1 || widths[i] < 1) return fail(c, HCTR_ERR_SHAPE, "image %d: empty source", i);
+        // cv2.resize asserts !dsize.empty(): a line so narrow that int(128 * w / h) == 0 fails there too
+        if (out_widths[i] < 1) return fail(c, HCTR_ERR_SHAPE, "image %d: destination width %d < 1", i, out_widths[i]);
+        const int64_t bytes = (int64_t)heights[i] * widths[i] * (ch < 0 ? -ch : ch);
+        if (offsets[i] < 0 || offsets[i] + bytes > packed_bytes)
+            return fail(c, HCTR_ERR_ARG, "image %d: [%lld, +%lld) outside the packed buffer of %lld bytes", i,
+                        (long long)offsets[i], (long long)bytes, (long long)packed_bytes);
+        ResizeLine& L = lines[(size_t)i];
+        L.src_off = offsets[i];
+        L.sh = heights[i];
+        L.sw = widths[i];
+        L.ch = ch;
+        L.dw = out_widths[i];
+        // dispatch of cv::resize for INTER_AREA (oracle/resize_ref.py resize_area)
+        L.inv_x = (double)L.dw / (double)L.sw;
+        L.inv_y = (double)out_height / (double)L.sh;
+        L.scale_x = 1.0 / L.inv_x;
+        L.scale_y = 1.0 / L.inv_y;
+        L.ix = (int)std::nearbyint(L.scale_x);
+        L.iy = (int)std::nearbyint(L.scale_y);
+        if (L.scale_x >= 1.0 && L.scale_y >= 1.0) {
+            const bool fast = std::fabs(L.scale_x - L.ix) < DBL_EPSILON && std::fabs(L.scale_y - L.iy) < DBL_EPSILON;
+            L.mode = fast ? 1 : 0;
+        } else {
+            L.mode = 2;
+        }
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<void*> tmp;
+    uint8_t *src = nullptr, *dst = nullptr;
+    ResizeLine* dl = nullptr;
+    int rc = dev_alloc(c, tmp, &src, (size_t)std::max<int64_t>(packed_bytes, 1), false);
+    if (rc == HCTR_OK) rc = dev_alloc(c, tmp, &dl, (size_t)n, false);
+    const size_t out_bytes = (size_t)n * out_height * out_W;
+    if (rc == HCTR_OK && !out_on_device) rc = dev_alloc(c, tmp, &dst, out_bytes, false);
+    if (rc == HCTR_OK) {
+        uint8_t* target = out_on_device ? out : dst;
+        hipError_t e = hipMemcpyAsync(src, packed_src, (size_t)packed_bytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(dl, lines.data(), sizeof(ResizeLine) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = launch_resize_lines(src, dl, n, target, out_height, out_W, c->stream);
+        if (e == hipSuccess && !out_on_device)
+            e = hipMemcpyAsync(out, dst, out_bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "resize_lines: %s", hipGetErrorString(e));
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));

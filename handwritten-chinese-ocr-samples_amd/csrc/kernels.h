@@ -98,4 +98,18 @@ hipError_t launch_row_candidates(const float* logits, int64_t ld, int B, int W, 
 // contiguous rows [rows][C] -> float32 log-softmax per row
 hipError_t launch_log_softmax_rows(const float* x, int64_t rows, int C, float* y, hipStream_t s);
 
+// ---- line preprocessing (preprocess.hip): cv2.resize(..., INTER_AREA) of ragged u8 images to height out_h ----
+struct ResizeLine {
+    int64_t src_off;          // byte offset of the image inside the packed source buffer
+    int32_t sh, sw;           // source height, width
+    int32_t ch;               // 1 = gray, 3 = BGR (cv2.imread order), -3 = RGB (PIL order)
+    int32_t dw;               // destination width (columns >= dw of the line's output row are zeroed)
+    int32_t mode;             // 0 area, 1 integer decimation (ix, iy), 2 enlarging bilinear variant
+    int32_t ix, iy;
+    double scale_x, scale_y;  // 1 / inv_*
+    double inv_x, inv_y;      // dw / sw, out_h / sh
+};
+hipError_t launch_resize_lines(const uint8_t* packed, const ResizeLine* lines, int n, uint8_t* out, int out_h, int out_w,
+                               hipStream_t s);
+
 }  // namespace hctr

@@ -27,13 +27,23 @@ __device__ __forceinline__ void glds16_asm(const char* gsrc, char* lds_dst) {
                  : "memory");
 }
 
+// Same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (no 64-bit VALU address).
+__device__ __forceinline__ void glds16_asm_s(const char* sbase, uint32_t voff, char* lds_dst) {
+    const uint32_t lds = (uint32_t)(uintptr_t)((lptr_t)lds_dst);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds)
+                 : "memory");
+}
+
 // -------------------------------------------------------------------------------------------
 // Shared epilogue of the MFMA conv kernels: + folded-BN bias, optional SE partial sums, ReLU,
 // (2,1) max-pool, zeroing of columns >= W, fp16 NHWC store (or fp32 rows in linear mode).
 // lane (q, c): for cout block cb (64 couts) the lane owns couts q*16 + jj*4 + i (jj = j & 3), i.e.
 // 16 consecutive couts, of pixel column c and pixel repeat n.
 // -------------------------------------------------------------------------------------------
-template <int WN, int WM, int JT, bool LINEAR, bool SPLIT>
+template <int WN, int WM, int JT, bool LINEAR, bool SPLIT, bool PRIVATE_RED = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT][4], char* smem, int tid, int lane,
                                               int wn, int wm, int n0, int mt, int img, int th, int tw, int hbase,
                                               int w0) {
@@ -142,8 +152,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
     if (a.se_part != nullptr) {
         // per-(image, channel) sums of the stored values over this block's pixels, fixed reduction
         // order (deterministic: lane tree -> LDS -> one partial row per block; no float atomics).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a trailing LDS-DMA (if any) has landed
-        __syncthreads();                       // main-loop LDS no longer needed
+        if (!PRIVATE_RED) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a trailing LDS-DMA (if any) has landed
+            __syncthreads();                   // main-loop LDS no longer needed
+        }
         float* red = (float*)smem;             // [WM][BN]
 #pragma unroll
         for (int j = 0; j < JT; ++j)
@@ -622,7 +634,7 @@ constexpr int kHalo4Lds = 2 * 16384 + kHaloBytes;          // 78848
 
 // GEOM 0: 16 rows x 16 columns (halo 18 x 18, row stride 20); GEOM 1: 8 rows x 32 columns for the
 // H = 8 stage (halo 10 x 34, row stride 36). Both strides are 4 (mod 8) and both halos are 360 rows.
-template <int GEOM, bool SPLIT>
+template <int GEOM, bool SPLIT, bool PERSIST>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a) {
     constexpr int WN = 1, WM = 4, JT = 8, BN = 128;
     constexpr int TR = GEOM ? 8 : 16, TC = GEOM ? 32 : 16;       // tile rows / columns
@@ -633,150 +645,226 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv;
-
-    const int total = a.mtiles * a.ntiles;
-    int lin;
-    {
-        const int id = blockIdx.x, xcd = id & 7, s = id >> 3;
-        const int q = total >> 3, r = total & 7;
-        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + s;
-    }
-    const int nt = lin % a.ntiles;
-    const int mt = lin / a.ntiles;
-    const int n0 = nt * BN;
-    const int tw = mt % a.tilesW;
-    const int t2 = mt / a.tilesW;
-    const int th = t2 % a.tilesH;
-    const int img = t2 / a.tilesH;
     const int cin = a.Cin;
     const int nkc = cin / kBK;
+    const int nk = 9 * nkc;
 
-    const char* xbase = (const char*)(a.x + img * a.in_sb + (int64_t)(th * TR) * a.in_sh + (int64_t)(tw * TC) * cin);
+    // ---- tiles of this workgroup. Every XCD owns a contiguous run of the (pixel-tile major, cout-tile
+    //      minor) order. Non-persistent: one tile per workgroup. Persistent: the workgroups of an XCD
+    //      stride through its run, and a workgroup prefetches its NEXT tile's first halo and weights
+    //      while the current tile's epilogue runs (the cold per-tile prologue is ~10-30 % of a launch).
+    const int total = a.mtiles * a.ntiles;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tq = total >> 3, tr = total & 7;
+    const int xbase_lin = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int xcnt = tq + (xcd < tr ? 1 : 0);
+    const int nloc = PERSIST ? (int)(gridDim.x >> 3) : 1;
+    struct Tile { int n0, mt; const char* xb; const char* wb; };
+    auto tile_at = [&](int idx) {
+        Tile t;
+        const int lin = xbase_lin + idx;
+        const int nt = lin % a.ntiles;
+        t.mt = lin / a.ntiles;
+        t.n0 = nt * BN;
+        const int tw = t.mt % a.tilesW;
+        const int t2 = t.mt / a.tilesW;
+        const int th = t2 % a.tilesH;
+        const int img = t2 / a.tilesH;
+        t.xb = (const char*)(a.x + img * a.in_sb + (int64_t)(th * TR) * a.in_sh + (int64_t)(tw * TC) * cin);
+        t.wb = (const char*)(a.w + (int64_t)t.n0 * cin);
+        return t;
+    };
+    int tidx = local;
+    if (tidx >= xcnt) return;                       // (persistent grids may exceed a short XCD run)
+
     const int wrow = GEOM ? (wm >> 1) * 4 : wm * 4;               // this wave's 4 x 16 patch inside the tile
     const int wcol = GEOM ? (wm & 1) * 16 : 0;
-    const char* wbase = (const char*)(a.w + (int64_t)n0 * cin);
     uint32_t woff[4], hoff[12];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int g = (wv * 4 + i) * 64 + lane;
-        const int row = g >> 3, cp = (g & 7) ^ (row & 7);
-        woff[i] = (uint32_t)row * (uint32_t)cin * 2u + cp * 16;
-    }
-#pragma unroll
-    for (int r = 0; r < 12; ++r) {                          // piece wv + 4r
-        const int g = (wv + 4 * r) * 64 + lane;
-        const int row = g >> 3, cp = (g & 7) ^ (row & 7);
-        int hy = row / S, hx = row - hy * S;
-        if (hx > TC + 1) hx = TC + 1;                       // pad columns: any valid address
-        if (hy > TR + 1) hy = TR + 1;                       // pieces >= 45 are never issued
-        hoff[r] = ((uint32_t)hy * (uint32_t)a.in_sh + (uint32_t)hx * (uint32_t)cin) * 2u + cp * 16;
-    }
     const int q = lane >> 4, c = lane & 15;
     const int aoff0 = c * 128 + (((0 + q) ^ (lane & 7)) << 4);
     const int aoff1 = c * 128 + (((4 + q) ^ (lane & 7)) << 4);
 
-    auto stage_weights = [&](int kc, int tap, int buf) {
-        const char* src = wbase + ((int64_t)tap * a.CoutPad * cin + (int64_t)kc * kBK) * 2;
+    auto stage_weights = [&](const char* wb, int kc, int tap, int buf) {
+        const char* src = wb + ((int64_t)tap * a.CoutPad * cin + (int64_t)kc * kBK) * 2;
         char* dst = smem + buf * 16384 + (wv * 4) * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16_asm(src + woff[i], dst + i * 1024);
+        for (int i = 0; i < 4; ++i) glds16_asm_s(src, woff[i], dst + i * 1024);
     };
-    auto stage_halo = [&](int kc) {
-        const char* src = xbase + (int64_t)kc * (kBK * 2);
+    auto stage_halo = [&](const char* xb, int kc) {
+        const char* src = xb + (int64_t)kc * (kBK * 2);
 #pragma unroll
         for (int r = 0; r < 12; ++r)
-            if (wv + 4 * r < kHaloPieces) glds16_asm(src + hoff[r], smem + 32768 + (wv + 4 * r) * 1024);
+            if (wv + 4 * r < kHaloPieces) glds16_asm_s(src, hoff[r], smem + 32768 + (wv + 4 * r) * 1024);
     };
-
-    f32x4 acc[JT][4];
-#pragma unroll
-    for (int j = 0; j < JT; ++j)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    stage_halo(0);
-    stage_weights(0, 0, 0);
     const int hbuf = 32768 + wrow * (S * 128);
 
-    for (int kc = 0; kc < nkc; ++kc) {
-        const bool next_chunk = kc + 1 < nkc;
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            const int k = kc * 9 + tap;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const int tdy = tap / 3, dx = tap - tdy * 3 - 1;
-            const int u = wcol + c + 1 + dx;
-            const int v0 = u * 128 + (((q ^ (u & 7) ^ ((tdy & 1) << 2)) & 7) << 4);
-            const char* hb = smem + hbuf + tdy * (S * 128);
-            const char* be = hb + v0;
-            const char* bo = hb + (v0 ^ 64);
-            const char* wt = smem + (k & 1) * 16384;
-            f16x8 ar[3][2], bq[2][4];
-            auto read_a = [&](int g, f16x8 (&dst)[2]) {
-                const int ks = g >> 2, jp = g & 3;
-                const char* base = wt + (ks ? aoff1 : aoff0);
-                dst[0] = *(const f16x8*)(base + (2 * jp) * 2048);
-                dst[1] = *(const f16x8*)(base + (2 * jp + 1) * 2048);
-            };
-            auto read_b = [&](int ks, f16x8 (&dst)[4]) {
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    dst[n] = *(const f16x8*)((((n & 1) ^ ks) ? bo : be) + n * (S * 128));
-            };
-            __builtin_amdgcn_sched_barrier(0);
-            read_b(0, bq[0]);
-            read_a(0, ar[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            read_a(1, ar[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            {   // next K step's weights (clamped on the very last step: re-stages into the idle buffer)
-                int kc1 = kc, tap1 = tap + 1;
-                if (tap1 == 9) { tap1 = 0; kc1 = next_chunk ? kc + 1 : kc; }
-                stage_weights(kc1, tap1, (k + 1) & 1);
+    Tile cur = tile_at(tidx);
+    int kbase = 0;                                  // weight-buffer parity continues across tiles
+    bool first = true;
+
+    for (;;) {
+        const bool has_next = PERSIST && (tidx + nloc < xcnt);
+        const char* nxb = cur.xb;
+        const char* nwb = cur.wb;
+        if (has_next) {
+            const Tile t = tile_at(tidx + nloc);
+            nxb = t.xb;
+            nwb = t.wb;
+        }
+        if (PERSIST || first) {      // per-lane DMA offsets: recomputed per tile so they are dead in the epilogue
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+        #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int g = (wv * 4 + i) * 64 + ln;
+                const int row = g >> 3, cp = (g & 7) ^ (row & 7);
+                woff[i] = (uint32_t)row * (uint32_t)cin * 2u + cp * 16;
             }
-            __builtin_amdgcn_sched_barrier(0);
+        #pragma unroll
+            for (int r = 0; r < 12; ++r) {                          // piece wv + 4r
+                const int g = (wv + 4 * r) * 64 + ln;
+                const int row = g >> 3, cp = (g & 7) ^ (row & 7);
+                int hy = row / S, hx = row - hy * S;
+                if (hx > TC + 1) hx = TC + 1;                       // pad columns: any valid address
+                if (hy > TR + 1) hy = TR + 1;                       // pieces >= 45 are never issued
+                hoff[r] = ((uint32_t)hy * (uint32_t)a.in_sh + (uint32_t)hx * (uint32_t)cin) * 2u + cp * 16;
+            }
+        }
+        if (first) {
+            stage_halo(cur.xb, 0);
+            stage_weights(cur.wb, 0, 0, 0);
+            first = false;
+        }
+
+        f32x4 acc[JT][4];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int ks = g >> 2, jp = g & 3;
-                if (g + 2 < 8) read_a(g + 2, ar[(g + 2) % 3]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (g == 1) { read_b(1, bq[1]); __builtin_amdgcn_sched_barrier(0); }
-                __builtin_amdgcn_s_setprio(1);
+        for (int j = 0; j < JT; ++j)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
+            for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int kc = 0; kc < nkc; ++kc) {
+            const bool next_chunk = kc + 1 < nkc;
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const int k = kc * 9 + tap;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const int tdy = tap / 3, dx = tap - tdy * 3 - 1;
+                const int u = wcol + c + 1 + dx;
+                const int v0 = u * 128 + (((q ^ (u & 7) ^ ((tdy & 1) << 2)) & 7) << 4);
+                const char* hb = smem + hbuf + tdy * (S * 128);
+                const char* be = hb + v0;
+                const char* bo = hb + (v0 ^ 64);
+                const char* wt = smem + ((kbase + k) & 1) * 16384;
+                f16x8 ar[3][2], bq[2][4];
+                auto read_a = [&](int g, f16x8 (&dst)[2]) {
+                    const int ks = g >> 2, jp = g & 3;
+                    const char* base = wt + (ks ? aoff1 : aoff0);
+                    dst[0] = *(const f16x8*)(base + (2 * jp) * 2048);
+                    dst[1] = *(const f16x8*)(base + (2 * jp + 1) * 2048);
+                };
+                auto read_b = [&](int ks, f16x8 (&dst)[4]) {
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
-                        acc[2 * jp + jj][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[g % 3][jj], bq[ks][n],
-                                                                                    acc[2 * jp + jj][n], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
+                        dst[n] = *(const f16x8*)((((n & 1) ^ ks) ? bo : be) + n * (S * 128));
+                };
                 __builtin_amdgcn_sched_barrier(0);
+                read_b(0, bq[0]);
+                read_a(0, ar[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                read_a(1, ar[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                {   // the next K step's weights into the other buffer; on a tile's last step that is the
+                    // next tile's first step (persistent), else a harmless re-stage into the idle buffer
+                    const int nb = (kbase + k + 1) & 1;
+                    if (k + 1 < nk) {
+                        int kc1 = kc, tap1 = tap + 1;
+                        if (tap1 == 9) { tap1 = 0; kc1 = kc + 1; }
+                        stage_weights(cur.wb, kc1, tap1, nb);
+                    } else if (has_next) {
+                        stage_weights(nwb, 0, 0, nb);
+                    } else {
+                        stage_weights(cur.wb, kc, tap, nb);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const int ks = g >> 2, jp = g & 3;
+                    if (g + 2 < 8) read_a(g + 2, ar[(g + 2) % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g == 1) { read_b(1, bq[1]); __builtin_amdgcn_sched_barrier(0); }
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc[2 * jp + jj][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                ar[g % 3][jj], bq[ks][n], acc[2 * jp + jj][n], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if ((next_chunk || has_next) && !(a.dbg & 32)) {     // dbg 32: timing experiment without the reload
+                // single halo buffer: every wave has consumed its last B fragments of this chunk (they fed
+                // the MFMAs above), so after this barrier the buffer may be overwritten - with the next
+                // chunk, or with the next tile's first chunk (whose latency then hides behind the epilogue).
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (next_chunk) stage_halo(cur.xb, kc + 1);
+                else stage_halo(nxb, 0);
             }
         }
-        if (next_chunk && !(a.dbg & 32)) {              // dbg 32: timing experiment without the reload
-            // single halo buffer: every wave has consumed its last B fragments of this chunk (they fed the
-            // MFMAs above), so after this barrier the buffer may be overwritten with the next chunk.
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            stage_halo(kc + 1);
+        // the epilogue's scratch (SE partial sums) lives after the DMA buffers, so DMA may stay in flight
+        {
+            const int tw = cur.mt % a.tilesW;
+            const int t2 = cur.mt / a.tilesW;
+            const int th = t2 % a.tilesH;
+            const int img = t2 / a.tilesH;
+            conv_epilogue<WN, WM, JT, false, SPLIT, true>(a, acc, smem + kHalo4Lds, tid, lane, 0, wm, cur.n0, cur.mt,
+                                                          img, th, tw, th * TR + wrow, tw * TC + wcol);
         }
+        if (!has_next) break;
+        kbase += nk;
+        tidx += nloc;
+        cur = tile_at(tidx);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last (redundant) weight DMA has landed
-    conv_epilogue<WN, WM, JT, false, SPLIT>(a, acc, smem, tid, lane, 0, wm, n0, mt, img, th, tw, th * TR + wrow,
-                                            tw * TC + wcol);
 }
 
-template <int GEOM, bool SPLIT>
-static hipError_t launch_conv_halo4_t(const ConvArgs& a0, hipStream_t s) {
+constexpr int kHalo4LdsTotal = kHalo4Lds + 4 * 128 * 4;   // + [WM][BN] floats of epilogue scratch
+
+template <int GEOM, bool SPLIT, bool PERSIST>
+static hipError_t launch_conv_halo4_tp(const ConvArgs& a0, hipStream_t s) {
     static bool done[64] = {};
-    hipError_t e0 = raise_lds_limit((const void*)conv3x3_halo4_kernel<GEOM, SPLIT>, kHalo4Lds, done);
+    hipError_t e0 = raise_lds_limit((const void*)conv3x3_halo4_kernel<GEOM, SPLIT, PERSIST>, kHalo4LdsTotal, done);
     if (e0 != hipSuccess) return e0;
     static const int dbg = [] { const char* e = getenv("HCTR_DBG"); return e ? atoi(e) : 0; }();
     ConvArgs a = a0;
     a.dbg = dbg;
-    hipLaunchKernelGGL((conv3x3_halo4_kernel<GEOM, SPLIT>), dim3(a.mtiles * a.ntiles), dim3(256), kHalo4Lds, s, a);
+    int grid = a.mtiles * a.ntiles;
+    if (PERSIST) {
+        static int cus[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && cus[dev] == 0) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus[dev] = prop.multiProcessorCount;
+            if (cus[dev] <= 0) cus[dev] = 256;
+        }
+        const int resident = 2 * ((dev >= 0 && dev < 64) ? cus[dev] : 256);     // two workgroups per CU
+        if (grid > resident) grid = resident;
+        grid = (grid + 7) / 8 * 8;                         // whole XCD rounds (extra workgroups exit at once)
+    }
+    hipLaunchKernelGGL((conv3x3_halo4_kernel<GEOM, SPLIT, PERSIST>), dim3(grid), dim3(256), kHalo4LdsTotal, s, a);
     return hipGetLastError();
+}
+template <int GEOM, bool SPLIT>
+static hipError_t launch_conv_halo4_t(const ConvArgs& a, hipStream_t s) {
+    // persistent tiles measured 6-8 % SLOWER on every layer (r01): kept for A/B only
+    static const bool persist = [] { const char* e = getenv("HCTR_PERSIST"); return e ? atoi(e) != 0 : false; }();
+    return persist ? launch_conv_halo4_tp<GEOM, SPLIT, true>(a, s) : launch_conv_halo4_tp<GEOM, SPLIT, false>(a, s);
 }
 template <int GEOM>
 static hipError_t launch_conv_halo4(const ConvArgs& a, hipStream_t s) {

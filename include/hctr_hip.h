@@ -171,6 +171,24 @@ int hctr_beam_search(const hctr_beam_params* p, int W, int B, int C, int k,
                      const float* full_logp_wbc,
                      int32_t* out_labels, int32_t* out_lengths, int32_t* line_status);
 
+/* ---- line preprocessing on the device: replaces read_resize_image / pil_loader -----------------
+ * test.py:207-216 (cv2.cvtColor BGR2GRAY + cv2.resize(src, (tw, 128), interpolation=cv2.INTER_AREA)) and
+ * utils/dataset.py:47-60 (the same resize inside ImageDataset.pil_loader). Image files are decoded by
+ * the caller; this call takes the decoded u8 pixels of n ragged images packed back to back in one host
+ * buffer (image i: heights[i] x widths[i] x |channels[i]| bytes at offsets[i]; channels 1 = gray,
+ * 3 = BGR as cv2.imread returns it, -3 = RGB as PIL returns it), converts colour to gray, resizes image i
+ * to out_height x out_widths[i] and writes it into row i of out[n][out_height][out_W] (uint8). Columns
+ * >= out_widths[i] are zero - hctr_greedy / hctr_forward_logits replicate the last real column from
+ * `widths`, which is NormalizePAD, utils/dataset.py:83-93; columns >= out_W of a wider line are dropped,
+ * which is AlignCollate's max_width crop, utils/dataset.py:118-145 (pass widths min(out_widths[i], out_W)
+ * on). out may be device memory (out_on_device), so the resized batch feeds hctr_greedy without touching
+ * the host again.
+ * Pixel parity with OpenCV is unpinned (opencv-python is not installed here): the kernel follows the
+ * published OpenCV 4.x algorithm as restated in oracle/resize_ref.py and is bit-exact against that. */
+int hctr_resize_lines(hctr_ctx* ctx, const uint8_t* packed_src, int64_t packed_bytes, const int64_t* offsets,
+                      const int32_t* heights, const int32_t* widths, const int32_t* channels, int n,
+                      int out_height, const int32_t* out_widths, int out_W, uint8_t* out, int out_on_device);
+
 /* ---- introspection used by bench.py / tests ---------------------------------------------------
  * Per-layer device time of the last forward (HIP events on the context's stream), in call order.
  * names: '\n'-separated layer names written into buf (cap bytes); ms: float array of n entries.

@@ -8,8 +8,11 @@ Differences from the reference, by design:
     there is no CPU execution path;
   * batches go through the fused device path (uint8 images + widths -> labels); the 29 kB-per-column
     logits never reach the host;
-  * images are read with PIL (cv2 is not a dependency); keep-ratio resize to height 128 uses bilinear
-    interpolation - pixel parity with cv2.INTER_AREA (test.py:204-216) is unpinned (DESIGN.md section 2);
+  * images are decoded with PIL (cv2 is not a dependency); gray conversion and the keep-ratio INTER_AREA
+    resize to height 128 (test.py:204-216, utils/dataset.py:47-60) run on the device and the batch stays in
+    HBM - pixel parity with cv2 is unpinned (DESIGN.md section 2);
+  * ``-bm`` applies AlignCollate's width cap of 1600 columns with its proportional label cut
+    (utils/dataset.py:111-148, built with the default max_width at test.py:235);
   * ``-f synthetic[:seed]`` loads the package's deterministic synthetic checkpoint (no checkpoint files
     are bundled with the reference), and then the vocabulary defaults to the synthetic one;
   * ``-kp zero|toy`` selects a built-in language model for beam search when kenlm is not installed.
@@ -25,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 IMG_EXT = (".jpg", ".jpeg", ".png", ".bmp")
+ALIGN_MAX_WIDTH = 1600            # AlignCollate(max_width=1600), utils/dataset.py:112, as built at test.py:235
 
 
 def build_argparser():
@@ -79,26 +83,17 @@ def find_characters(input_path, synthetic):
     raise FileNotFoundError("chars_list.txt not found (looked in: %s)" % ", ".join(cands))
 
 
-def read_resize_image(path, height):
-    from PIL import Image
-    im = Image.open(path).convert("L")
-    tw = max(1, int(height * (float(im.size[0]) / float(im.size[1]))))
-    return np.asarray(im.resize((tw, height), Image.BILINEAR), dtype=np.uint8)
-
-
 def list_inputs(path):
-    if os.path.isfile(path):
-        return [path]
-    return [os.path.join(path, n) for n in sorted(os.listdir(path)) if n.lower().endswith(IMG_EXT)]
+    import hctr_amd
+    return hctr_amd.preprocess.list_inputs(path)
 
 
-def pad_batch(images):
-    """[B,128,maxW] uint8 + widths; the engine applies NormalizePAD's replicate pad (utils/dataset.py:83-93)."""
-    widths = np.array([im.shape[1] for im in images], dtype=np.int32)
-    out = np.zeros((len(images), 128, int(widths.max())), dtype=np.uint8)
-    for i, im in enumerate(images):
-        out[i, :, :im.shape[1]] = im
-    return out, widths
+def load_batch(model, paths, rule, max_width=None):
+    """Decode on the host, then gray + INTER_AREA resize + packing on the device; the batch stays in HBM."""
+    import hctr_amd
+    pp = hctr_amd.preprocess
+    return pp.resize_lines(model, [pp.load_image(p) for p in paths], model.img_height, rule, "rgb", max_width,
+                           device_out=True)
 
 
 def edit_distance(a, b):
@@ -161,10 +156,9 @@ def test(args):
     if args.benchmark_mode:
         return benchmark(model, codec, args)
     paths = list_inputs(args.input)
-    images = [read_resize_image(p, model.img_height) for p in paths]
-    for i in range(len(images) // args.batch_size):
+    for i in range(len(paths) // args.batch_size):
         print("batch {} is being processed...".format(i))
-        imgs, widths = pad_batch(images[i * args.batch_size:(i + 1) * args.batch_size])
+        imgs, widths = load_batch(model, paths[i * args.batch_size:(i + 1) * args.batch_size], "test")
         t0 = time.time()
         result = recognise(model, codec, imgs, widths)
         dt = time.time() - t0
@@ -178,6 +172,8 @@ def benchmark(model, codec, args):
     ``<input>/test/``; utils/dataset.py:31-37)."""
     if not os.path.isdir(args.input):
         raise AssertionError("Input should be a folder under benchmark mode.")
+    import hctr_amd
+    pp = hctr_amd.preprocess
     gt = os.path.join(args.input, "test_img_id_gt.txt")
     items = []
     with open(gt, "r", encoding="utf-8") as f:
@@ -196,8 +192,10 @@ def benchmark(model, codec, args):
     t_all = time.time()
     for i in range(0, len(items), args.batch_size):
         chunk = items[i:i + args.batch_size]
-        images = [read_resize_image(n, model.img_height) for n, _ in chunk]
-        imgs, widths = pad_batch(images)
+        arrs = [pp.load_image(n) for n, _ in chunk]
+        full = [pp.target_width(a.shape[0], a.shape[1], model.img_height, "dataset") for a in arrs]
+        imgs, widths = pp.resize_lines(model, arrs, model.img_height, "dataset", "rgb", ALIGN_MAX_WIDTH, device_out=True)
+        chunk = [(n, pp.truncate_label(tru, fw, int(imgs.shape[2]))) for (n, tru), fw in zip(chunk, full)]
         t0 = time.time()
         result = recognise(model, codec, imgs, widths)
         for j, (pre, (_, tru)) in enumerate(zip(result, chunk)):

@@ -342,6 +342,22 @@ def test_cli_reference_flags(tmp_path, engine, codec, synth):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.count("predicted results: ") == 2
+    # half-height files: INTER_AREA enlarging x2 replicates pixels (device resize inside the CLI)
+    small = tmp_path / "small"
+    small.mkdir()
+    halves = [im[::2, ::2] for im in imgs[:2]]
+    for i, im in enumerate(halves):
+        Image.fromarray(im).save(small / ("%06d.png" % i))
+    up = [np.repeat(np.repeat(h, 2, axis=0), 2, axis=1) for h in halves]
+    w = max(u.shape[1] for u in up)
+    batch = np.zeros((2, 128, w), np.uint8)
+    for j, u in enumerate(up):
+        batch[j, :, :u.shape[1]] = u
+    want_up = codec.labels_to_text(engine.greedy(batch, widths=np.array([u.shape[1] for u in up], np.int32)))
+    r = subprocess.run(base + ["-i", str(small), "-dm", "greedy-search"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = [ln for ln in r.stdout.splitlines() if ln.startswith("predicted results: ")]
+    assert ast.literal_eval(got[0][len("predicted results: "):]) == want_up
     arpa = codec_cases.write_toy_arpa(str(tmp_path / "toy.arpa"))                  # -kp model.arpa: native LM
     r = subprocess.run(base + ["-i", str(data / "test"), "-dm", "beam-search", "-kp", arpa], capture_output=True,
                        text=True, timeout=600)
@@ -516,3 +532,65 @@ def test_full_size_config2_properties(engine, codec, synth):
     logits = engine(sub)                                                           # [2000, 4, 7358]
     assert codec.decode(logits) == codec.labels_to_text(labels[:4])               # fused == decode(logits)
     assert np.isfinite(logits).all()
+
+
+@pytest.mark.parametrize("env", [{"HCTR_HALO": "0"}, {"HCTR_HALO": "1"}, {"HCTR_HALO": "0", "HCTR_PIPE": "1"},
+                                 {"HCTR_FUSE_SE": "0"}, {"HCTR_HALO": "0", "HCTR_BIG_TILES": "0"},
+                                 {"HCTR_PERSIST": "1"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_alternative_kernel_paths(env):
+    """The A/B kernels (generic 64x256/128x128/256x256 tiles, 8-wave halo, interleaved pipe, unfused SE,
+    persistent tiles) stay correct: same fixture and tolerances as the default path. Kernel selection is
+    read once per process, hence one child process per variant (run one after the other)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_altpath_check.py")], env=e,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_device_resize_bit_exact(engine, pkg, codec):
+    """csrc/preprocess.hip (through hctr_resize_lines) vs oracle/resize_ref.py: every byte equal, for all three
+    OpenCV INTER_AREA regimes (area, integer decimation, enlarging), gray / BGR / RGB sources, ragged batches,
+    one-pixel sources, the AlignCollate crop; the device-resident batch decodes like the host one."""
+    from oracle import resize_ref
+    pp = pkg.preprocess
+    rng = np.random.default_rng(77)
+    shapes = [(48, 131), (53, 37), (77, 115), (127, 90), (128, 33), (129, 300), (200, 777), (256, 154), (384, 60),
+              (300, 41), (1, 9), (2, 2), (500, 31), (64, 1), (131, 257), (640, 1000)]
+    for rule in ("test", "dataset"):
+        imgs = [rng.integers(0, 256, hw, dtype=np.uint8) for hw in shapes]
+        got, widths = pp.resize_lines(engine, imgs, rule=rule)
+        assert got.dtype == np.uint8 and got.shape[:2] == (len(imgs), 128)
+        for i, im in enumerate(imgs):
+            want = resize_ref.read_resize(im, 128, rule)
+            assert widths[i] == want.shape[1]
+            assert np.array_equal(got[i, :, :widths[i]], want), (rule, shapes[i])
+            assert not got[i, :, widths[i]:].any()
+    # colour sources, both channel orders
+    col = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in ((60, 90), (200, 333), (128, 64))]
+    for order in ("rgb", "bgr"):
+        got, widths = pp.resize_lines(engine, col, order=order)
+        for i, im in enumerate(col):
+            assert np.array_equal(got[i, :, :widths[i]], resize_ref.read_resize(im, 128, "test", order))
+    # AlignCollate crop (utils/dataset.py:118-145)
+    wide = [rng.integers(0, 256, (64, 1000), dtype=np.uint8), rng.integers(0, 256, (64, 100), dtype=np.uint8)]
+    got, widths = pp.resize_lines(engine, wide, rule="dataset", max_width=1600)
+    assert got.shape == (2, 128, 1600) and widths.tolist() == [1600, 200]
+    assert np.array_equal(got[0], resize_ref.read_resize(wide[0], 128, "dataset")[:, :1600])
+    # device-resident output feeds the engine directly
+    lines = [rng.integers(0, 256, (50 + 7 * i, 260 + 40 * i), dtype=np.uint8) for i in range(3)]
+    host, widths = pp.resize_lines(engine, lines)
+    dev, widths_d = pp.resize_lines(engine, lines, device_out=True)
+    assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), host) and np.array_equal(widths, widths_d)
+    a = engine.greedy(host, widths=widths)
+    b = engine.greedy(dev, widths=widths)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # errors: cv2.resize raises on an empty destination, the shim raises ValueError
+    with pytest.raises(ValueError):
+        pp.resize_lines(engine, [np.zeros((500, 3), np.uint8)])           # int(128 * 3 / 500) == 0
+    with pytest.raises(ValueError):
+        pp.resize_lines(engine, [np.zeros((4, 4), np.float32)])
+    assert pp.resize_lines(engine, [])[0].shape == (0, 128, 0)
