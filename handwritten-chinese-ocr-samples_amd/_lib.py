@@ -120,6 +120,14 @@ def load():
             if not os.path.isfile(LIB_PATH):
                 raise RuntimeError("libhctr_hip.so is missing and could not be built with hipcc (%s); "
                                    "the hctr engine has no CPU fallback" % exc)
+    # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7 (same SONAME as /opt/rocm's).
+    # Loaded first, it is the copy this library binds to as well, so device pointers of torch tensors
+    # (on_device arguments, DLPack-free interop) and the engine's own allocations share a runtime; loaded
+    # second, torch would bring up a second runtime that finds no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, res, args in SIGNATURES:
         fn = getattr(lib, name)          # AttributeError if the ABI drifted from the header

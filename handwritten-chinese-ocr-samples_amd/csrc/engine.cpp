@@ -187,11 +187,12 @@ int need(hctr_ctx* c, const std::string& key, std::vector<int64_t> shape, const 
     return HCTR_OK;
 }
 
-// stored row s of a 64-row block holds cout perm64(s): MFMA tile j = s/16, row ra = s%16 of that
-// tile is cout (ra>>2)*16 + j*4 + (ra&3), so an accumulator lane owns 16 consecutive couts.
+// stored row s of a 64-row block holds cout perm64(s): MFMA tile j = s/16, row ra = s%16 (lane group
+// q = ra>>2, element i = ra&3) of that tile is cout (j>>1)*32 + q*8 + (j&1)*4 + i, so an accumulator lane
+// owns two runs of 8 consecutive couts and the four lanes of a pixel store 64 contiguous bytes at a time.
 inline int perm64(int s) {
     const int j = s >> 4, ra = s & 15;
-    return (ra >> 2) * 16 + j * 4 + (ra & 3);
+    return (j >> 1) * 32 + (ra >> 2) * 8 + (j & 1) * 4 + (ra & 3);
 }
 
 // Conv2d + eval BatchNorm2d folded: w' = w * g/sqrt(v+eps), b' = (b - mean) * g/sqrt(v+eps) + beta

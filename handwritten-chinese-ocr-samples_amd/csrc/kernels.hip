@@ -40,8 +40,8 @@ __device__ __forceinline__ void glds16_asm_s(const char* sbase, uint32_t voff, c
 // -------------------------------------------------------------------------------------------
 // Shared epilogue of the MFMA conv kernels: + folded-BN bias, optional SE partial sums, ReLU,
 // (2,1) max-pool, zeroing of columns >= W, fp16 NHWC store (or fp32 rows in linear mode).
-// lane (q, c): for cout block cb (64 couts) the lane owns couts q*16 + jj*4 + i (jj = j & 3), i.e.
-// 16 consecutive couts, of pixel column c and pixel repeat n.
+// lane (q, c): for cout block cb (64 couts) the lane owns couts (jj>>1)*32 + q*8 + (jj&1)*4 + i (jj = j & 3),
+// i.e. two runs of 8 consecutive couts, of pixel column c and pixel repeat n.
 // -------------------------------------------------------------------------------------------
 template <int WN, int WM, int JT, bool LINEAR, bool SPLIT, bool PRIVATE_RED = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT][4], char* smem, int tid, int lane,
@@ -51,11 +51,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
     constexpr int BN = WN * WC, BM = WM * 64;
     const int q = lane >> 4;
     const int c = lane & 15;
-    const int cw0 = n0 + wn * WC + q * 16;      // + cb*64 + jj*4 + i
+    const int cw0 = n0 + wn * WC + q * 8;       // + co(j) + i
+    // cout offset of accumulator tile j (cb = j>>2 the 64-cout block, jj = j&3): a lane owns two runs of 8
+    // consecutive couts per block, q*8.. (jj 0,1) and 32+q*8.. (jj 2,3), so the four lanes of a pixel write
+    // 64 contiguous bytes per store instruction (half a cache line without holes).
+    auto co = [](int j) { return (j >> 2) * 64 + ((j >> 1) & 1) * 32 + (j & 1) * 4; };
 
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
-        const f32x4 b4 = *(const f32x4*)(a.bias + cw0 + (j >> 2) * 64 + (j & 3) * 4);
+        const f32x4 b4 = *(const f32x4*)(a.bias + cw0 + co(j));
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -70,7 +74,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
             if (m < a.M) {
 #pragma unroll
                 for (int j = 0; j < JT; ++j)
-                    *(f32x4*)(out + m * a.ldo + cw0 + (j >> 2) * 64 + (j & 3) * 4) = acc[j][n];
+                    *(f32x4*)(out + m * a.ldo + cw0 + co(j)) = acc[j][n];
             }
         }
         return;
@@ -91,12 +95,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     const half_t* r = a.resid + pix0 + (int64_t)(hbase + n) * a.out_sh + cb * 64;
-                    const f16x8 h0 = *(const f16x8*)r, h1 = *(const f16x8*)(r + 8);
-                    const f16x8 l0 = *(const f16x8*)(r + a.Cout), l1 = *(const f16x8*)(r + a.Cout + 8);
+                    const f16x8 h0 = *(const f16x8*)r, h1 = *(const f16x8*)(r + 32);
+                    const f16x8 l0 = *(const f16x8*)(r + a.Cout), l1 = *(const f16x8*)(r + a.Cout + 32);
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const float rv = e < 8 ? (float)h0[e] + (float)l0[e] : (float)h1[e - 8] + (float)l1[e - 8];
-                        const float sv = sc[cb * 64 + e];
+                        const float sv = sc[cb * 64 + (e >> 3) * 32 + (e & 7)];
                         acc[cb * 4 + (e >> 2)][n][e & 3] = fmaf(acc[cb * 4 + (e >> 2)][n][e & 3], sv, rv);
                     }
                 }
@@ -104,7 +108,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
     } else if (a.se_scale != nullptr) {
         const float* sc = a.se_scale + (int64_t)img * a.Cout + cw0;
         if (w < a.out_wlimit) {
-            // all residual loads first (one latency exposure), 16 couts = 2 x 16 B per (cb, n)
+            // all residual loads first (one latency exposure), 2 x 8 couts = 2 x 16 B per (cb, n)
             f16x8 rlo[JT / 4][4], rhi[JT / 4][4];
 #pragma unroll
             for (int cb = 0; cb < JT / 4; ++cb)
@@ -112,11 +116,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
                 for (int n = 0; n < 4; ++n) {
                     const half_t* r = a.resid + pix0 + (int64_t)(hbase + n) * a.out_sh + cb * 64;
                     rlo[cb][n] = *(const f16x8*)r;
-                    rhi[cb][n] = *(const f16x8*)(r + 8);
+                    rhi[cb][n] = *(const f16x8*)(r + 32);
                 }
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
-                const f32x4 s4 = *(const f32x4*)(sc + (j >> 2) * 64 + (j & 3) * 4);
+                const f32x4 s4 = *(const f32x4*)(sc + co(j));
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -166,7 +170,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
                 s += __shfl_xor(s, 2);
                 s += __shfl_xor(s, 4);
                 s += __shfl_xor(s, 8);
-                if (c == 0) red[wm * BN + wn * WC + (j >> 2) * 64 + q * 16 + (j & 3) * 4 + i] = s;
+                if (c == 0) red[wm * BN + wn * WC + q * 8 + co(j) + i] = s;
             }
         __syncthreads();
         if (tid < BN) {
@@ -178,7 +182,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
         }
     }
 
-    if (w < a.out_wlimit) {
+    if (a.dbg & 256) {           // dbg 256: timing experiment without the output stores
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) t += acc[j][n][0] + acc[j][n][1] + acc[j][n][2] + acc[j][n][3];
+        if (t == 123.456f) out[0] = (half_t)t;
+    } else if (w < a.out_wlimit) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             if (a.pool && (n & 1)) continue;
@@ -193,7 +204,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
                     if (e < 8) lo[e] = hv; else hi[e - 8] = hv;
                 }
                 *(f16x8*)(o + cb * 64) = lo;
-                *(f16x8*)(o + cb * 64 + 8) = hi;
+                *(f16x8*)(o + cb * 64 + 32) = hi;
                 if (SPLIT) {                        // planes: [hi | lo | hi]
                     f16x8 l0, l1;
 #pragma unroll
@@ -203,9 +214,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
                         if (e < 8) l0[e] = lv; else l1[e - 8] = lv;
                     }
                     *(f16x8*)(o + a.Cout + cb * 64) = l0;
-                    *(f16x8*)(o + a.Cout + cb * 64 + 8) = l1;
+                    *(f16x8*)(o + a.Cout + cb * 64 + 32) = l1;
                     *(f16x8*)(o + 2 * a.Cout + cb * 64) = lo;
-                    *(f16x8*)(o + 2 * a.Cout + cb * 64 + 8) = hi;
+                    *(f16x8*)(o + 2 * a.Cout + cb * 64 + 32) = hi;
                 }
             }
         }
@@ -222,7 +233,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
 //
 // GEMM view: D[cout][pixel] = sum_{tap,cin} Wt[tap][cout][cin] * X[pixel + tap][cin]
 //   MFMA A operand = weights (rows = couts), B operand = pixels (cols), so every lane ends up with
-//   16 consecutive couts of one pixel = one 32-byte NHWC store.
+//   two runs of 8 consecutive couts of one pixel; the 4 lanes of a pixel store 64 contiguous bytes.
 // Block = WN x WM waves; each wave owns JT*16 couts x 64 pixels (JT x 4 MFMA tiles): 64 couts
 //   (64 fp32 acc regs) for the 64x256 and 128x128 block tiles, 128 couts for the 256x256 tile.
 //   conv mode: a wave's 64 pixels are a 4-row x 16-column patch; MFMA column c = image column,
@@ -646,7 +657,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv;
     const int cin = a.Cin;
-    const int nkc = cin / kBK;
+    const int nkc = (a.dbg & 64) ? 0 : cin / kBK;       // dbg 64: timing experiment without the K loop
     const int nk = 9 * nkc;
 
     // ---- tiles of this workgroup. Every XCD owns a contiguous run of the (pixel-tile major, cout-tile
@@ -742,6 +753,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        // Retire every scalar (kernarg) load before the loop. A load still pending at the loop header keeps
+        // hipcc's counter model "dirty" on every iteration (scalar loads return out of order), and it then
+        // drains lgkmcnt(0) at the first MFMA group of each K step instead of the counted wait.
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0), vmcnt/expcnt untouched
         for (int kc = 0; kc < nkc; ++kc) {
             const bool next_chunk = kc + 1 < nkc;
 #pragma unroll 1
@@ -776,17 +791,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 read_a(1, ar[1]);
                 __builtin_amdgcn_sched_barrier(0);
                 {   // the next K step's weights into the other buffer; on a tile's last step that is the
-                    // next tile's first step (persistent), else a harmless re-stage into the idle buffer
-                    const int nb = (kbase + k + 1) & 1;
-                    if (k + 1 < nk) {
-                        int kc1 = kc, tap1 = tap + 1;
-                        if (tap1 == 9) { tap1 = 0; kc1 = kc + 1; }
-                        stage_weights(cur.wb, kc1, tap1, nb);
-                    } else if (has_next) {
-                        stage_weights(nwb, 0, 0, nb);
-                    } else {
-                        stage_weights(cur.wb, kc, tap, nb);
-                    }
+                    // next tile's first step (persistent), else a harmless re-stage into the idle buffer.
+                    // Branch-free on purpose: a branch here makes hipcc drain lgkmcnt(0) at the merge point.
+                    const bool more = k + 1 < nk;
+                    const bool wrap = tap == 8;
+                    const int tap1 = more ? (wrap ? 0 : tap + 1) : (has_next ? 0 : tap);
+                    const int kc1 = more ? (wrap ? kc + 1 : kc) : (has_next ? 0 : kc);
+                    const char* wsrc = (more || !has_next) ? cur.wb : nwb;
+                    stage_weights(wsrc, kc1, tap1, (kbase + k + 1) & 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -817,6 +829,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             }
         }
         // the epilogue's scratch (SE partial sums) lives after the DMA buffers, so DMA may stay in flight
+        if (a.dbg & 128) {       // dbg 128: timing experiment without the epilogue (keeps the MFMAs alive)
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) t += acc[j][n][0] + acc[j][n][1] + acc[j][n][2] + acc[j][n][3];
+            if (t == 123.456f) ((half_t*)a.y)[0] = (half_t)t;
+        } else
         {
             const int tw = cur.mt % a.tilesW;
             const int t2 = cur.mt / a.tilesW;
@@ -1133,7 +1153,7 @@ __global__ __launch_bounds__(256) void se_premean_kernel(const float* __restrict
     __syncthreads();
     // cout c = cg*64 + cl is stored row blk*64 + s with perm64(s) = cl (engine.cpp perm64)
     const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int qq = cl >> 4, rem = cl & 15, jj = rem >> 2, ii = rem & 3;
+    const int jj = (cl >> 5) * 2 + ((cl >> 2) & 1), qq = (cl >> 3) & 3, ii = cl & 3;
     const int srow = jj * 16 + qq * 4 + ii;
     float acc = 0.f;
     const int kper = 9 * C / 4;                        // this slice's share of the 9*C reduction
