@@ -66,6 +66,8 @@ struct Workspace {
     float* se_border = nullptr;     // [B][4][8 segments][512]
     float* se_mean = nullptr;       // [B][512]
     int32_t* colidx = nullptr;      // [B*W]
+    float* amax_val = nullptr;      // [P][B*W] fused head argmax partials, P <= Cpad/64
+    int32_t* amax_idx = nullptr;
     int32_t* labels = nullptr;      // [B][W]
     int32_t* lengths = nullptr;     // [B]
     std::vector<void*> allocs;
@@ -107,6 +109,7 @@ struct hctr_ctx {
     bool split = false;
     int chm() const { return split ? 3 : 1; }      // channel multiplier of activation buffers
     bool fuse_se = true;
+    bool fuse_argmax = true;         // greedy: argmax in the head GEMM's epilogue (HCTR_FUSE_ARGMAX=0: separate pass)
     // profiling
     bool profiling = false;
     std::vector<ProfEntry> prof;
@@ -381,6 +384,8 @@ int ensure_workspace(hctr_ctx* c, int B, int W) {
     A(&ws.se_border, (size_t)B * 4 * 8 * 512, false);
     A(&ws.se_mean, (size_t)B * 512, false);
     A(&ws.colidx, (size_t)cols, false);
+    A(&ws.amax_val, (size_t)cols * (c->cpad / 64), false);
+    A(&ws.amax_idx, (size_t)cols * (c->cpad / 64), false);
     A(&ws.labels, (size_t)cols, false);
     A(&ws.lengths, (size_t)B, false);
     if (rc != HCTR_OK) {
@@ -523,9 +528,10 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
     return HCTR_OK;
 }
 
-// trunk + head for the staged batch in ws.img: leaves [B*W][cpad] fp32 logits in ws.logits.
-// ResNet.forward :115-153 and hctr_model.forward :171-176.
-int run_forward(hctr_ctx* c, int img_f32, bool have_widths) {
+// trunk + head for the staged batch in ws.img: leaves [B*W][cpad] fp32 logits in ws.logits, or - greedy
+// decode, fused_argmax - only the per-column argmax in ws.colidx (the 29 kB-per-column logits never exist).
+// ResNet.forward :115-153 and hctr_model.forward :171-176; np.argmax(preds, 2) utils/ctc_codec.py:75.
+int run_forward(hctr_ctx* c, int img_f32, bool have_widths, bool fused_argmax = false) {
     Workspace& ws = c->ws;
     Prof pf(c);
     if (c->profiling) { c->prof.clear(); c->ev_used = 0; }
@@ -567,6 +573,18 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths) {
     const ConvTile htile = (c->big_tiles && c->cpad % 256 == 0) ? TILE_256x256 : TILE_128x128;
     const int hbm = htile == TILE_256x256 ? 256 : 128;
     a.mtiles = (int)((a.M + hbm - 1) / hbm); a.ntiles = c->cpad / hbm;
+    if (fused_argmax) {
+        a.y = nullptr;
+        a.amax_val = ws.amax_val;
+        a.amax_idx = ws.amax_idx;
+        pf.begin("head.linear+argmax");
+        HIP_TRY(c, launch_conv(a, htile, 1, true, c->stream));
+        pf.end();
+        pf.begin("argmax_partials");
+        HIP_TRY(c, launch_argmax_partials(ws.amax_val, ws.amax_idx, a.ntiles * kLinearWN, a.M, ws.colidx, c->stream));
+        pf.end();
+        return HCTR_OK;
+    }
     pf.begin("head.linear");
     HIP_TRY(c, launch_conv(a, htile, 1, true, c->stream));
     pf.end();
@@ -646,6 +664,7 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
     if (const char* hm = getenv("HCTR_HALO")) c->halo_mode = atoi(hm);
     if (const char* pr = getenv("HCTR_PRECISION")) c->split = std::string(pr) == "f16x3";
     if (const char* fs = getenv("HCTR_FUSE_SE")) c->fuse_se = atoi(fs) != 0;
+    if (const char* fa = getenv("HCTR_FUSE_ARGMAX")) c->fuse_argmax = atoi(fa) != 0;
     if (const char* wb = getenv("HCTR_WS_BUDGET_GB")) {
         const long long v = atoll(wb);
         if (v > 0) c->ws_budget = (size_t)v << 30;
@@ -812,12 +831,14 @@ int hctr_greedy(hctr_ctx* c, const void* img, int img_dtype, int img_on_device, 
         const int nb = std::min(nbmax, B - b0);
         TRY(ensure_workspace(c, nb, W));
         TRY(stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W));
-        TRY(run_forward(c, img_dtype == HCTR_F32, widths != nullptr));
+        TRY(run_forward(c, img_dtype == HCTR_F32, widths != nullptr, c->fuse_argmax));
         Workspace& ws = c->ws;
         Prof pf(c);
-        pf.begin("argmax_rows");
-        HIP_TRY(c, launch_argmax_rows(ws.logits, c->cpad, (int64_t)nb * W, C, ws.colidx, 0, 0, c->stream));
-        pf.end();
+        if (!c->fuse_argmax) {
+            pf.begin("argmax_rows");
+            HIP_TRY(c, launch_argmax_rows(ws.logits, c->cpad, (int64_t)nb * W, C, ws.colidx, 0, 0, c->stream));
+            pf.end();
+        }
         pf.begin("ctc_collapse");
         HIP_TRY(c, launch_ctc_collapse(ws.colidx, nb, W, C, ws.labels, ws.lengths, c->stream));
         pf.end();

@@ -35,6 +35,11 @@ struct ConvArgs {
     int64_t M;              // linear mode: number of rows
     int64_t ldo;            // linear mode: output leading dimension (elements)
     int mtiles, ntiles;
+    // linear mode, fused greedy argmax (np.argmax(preds, 2), utils/ctc_codec.py:75): when amax_idx is set the
+    // logits are NOT stored; every wave column (nt, wn) writes its best (value, class) of each row to
+    // amax_val/amax_idx[(nt*WN + wn) * M + m]; launch_argmax_partials picks the first maximum per row.
+    float* amax_val;
+    int32_t* amax_idx;
     int split;              // f16x3 mode: activations are [hi | lo | hi] fp16 planes of Cout channels each
                             // (input side: Cin already counts the tripled channels)
     int dbg;                // timing experiments only (HCTR_DBG): 1 = DMA from fixed hot addresses, 2 = no DMA in the loop
@@ -51,6 +56,9 @@ inline int conv_tile_couts(ConvTile t) {
 }
 
 hipError_t launch_conv(const ConvArgs& a, ConvTile tile, int taps, bool linear_f32, hipStream_t s);
+constexpr int kLinearWN = 2;          // wave columns of both linear-mode tiles (partials per n-tile)
+// rows [P][M] of (value, class) partials -> idx[M]: first maximum, 0 for an all-(-inf)/NaN row
+hipError_t launch_argmax_partials(const float* val, const int32_t* cls, int P, int64_t M, int32_t* idx, hipStream_t s);
 size_t conv_lds_bytes(ConvTile tile);
 
 hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, const float* w9,

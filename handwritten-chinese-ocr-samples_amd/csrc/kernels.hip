@@ -66,6 +66,37 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
             for (int i = 0; i < 4; ++i) acc[j][n][i] += b4[i];
     }
 
+    if (LINEAR && a.amax_idx != nullptr) {
+        // fused greedy argmax: classes rise with (j, i) for a lane and with q, wn, nt beyond it, so a strict
+        // '>' keeps the first maximum inside a lane and the (value, class) merge keeps it across lanes.
+        static_assert(!LINEAR || WN == kLinearWN, "partials per n-tile");
+        const int64_t part = (int64_t)((n0 / BN) * WN + wn) * a.M;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cls = cw0 + co(j) + i;
+                    const float v = acc[j][n][i];
+                    if (cls < a.Cout && v > bv) { bv = v; bi = cls; }
+                }
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            const int64_t m = (int64_t)mt * BM + wm * 64 + n * 16 + c;
+            if (q == 0 && m < a.M) {
+                a.amax_val[part + m] = bv;
+                a.amax_idx[part + m] = bi;
+            }
+        }
+        return;
+    }
     if (LINEAR) {
         float* out = (float*)a.y;
 #pragma unroll
@@ -1314,6 +1345,27 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
         const int64_t o = tB > 0 ? (row % tB) * tW + row / tB : row;
         idx[o] = (bi == 0x7fffffff) ? 0 : bi;
     }
+}
+
+// second stage of the fused head argmax: thread per row over the P = ntiles * WN partials (class ranges rise with p)
+__global__ __launch_bounds__(256) void argmax_partials_kernel(const float* __restrict__ val, const int32_t* __restrict__ cls,
+                                                              int P, int64_t M, int32_t* __restrict__ idx) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int p = 0; p < P; ++p) {
+        const float v = val[(int64_t)p * M + m];
+        const int i = cls[(int64_t)p * M + m];
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+    idx[m] = (bi == 0x7fffffff) ? 0 : bi;
+}
+
+hipError_t launch_argmax_partials(const float* val, const int32_t* cls, int P, int64_t M, int32_t* idx, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(argmax_partials_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, val, cls, P, M, idx);
+    return hipGetLastError();
 }
 
 hipError_t launch_argmax_rows(const float* logits, int64_t ld, int64_t M, int C, int32_t* idx, int tB, int tW,
