@@ -104,6 +104,7 @@ SIGNATURES = [
     ("hctr_resize_lines", _I, [_VP, _VP, _I64, c_i64p, c_i32p, c_i32p, c_i32p, _I, _I, c_i32p, _I, _VP, _I]),
     ("hctr_set_profiling", _I, [_VP, _I]),
     ("hctr_last_profile", _I, [_VP, ctypes.c_char_p, _I, c_f32p, _I]),
+    ("hctr_debug_stamps", _I64, [_VP, ctypes.c_char_p, _VP, _I64]),
     ("hctr_debug_activation", _I64, [_VP, ctypes.c_char_p, _VP, _I64, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
 ]
 

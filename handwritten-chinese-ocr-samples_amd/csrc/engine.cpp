@@ -109,6 +109,9 @@ struct hctr_ctx {
     bool split = false;
     int chm() const { return split ? 3 : 1; }      // channel multiplier of activation buffers
     bool fuse_se = true;
+    std::string stamp_layer;         // hctr_debug_stamps: layer whose workgroups are time-stamped (diagnostic)
+    unsigned long long* stamp_buf = nullptr;
+    int64_t stamp_cap = 0, stamp_n = 0;
     bool fuse_argmax = true;         // greedy: argmax in the head GEMM's epilogue (HCTR_FUSE_ARGMAX=0: separate pass)
     // profiling
     bool profiling = false;
@@ -474,6 +477,11 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
     a.relu = relu; a.pool = pool;
     a.mtiles = ws.B * a.tilesH * a.tilesW;
     a.ntiles = cw.coutPad / conv_tile_couts(tile);
+    if (c->stamp_buf && c->stamp_layer == name && (tile == TILE_HALO4 || tile == TILE_HALO4_8x32) &&
+        (int64_t)a.mtiles * a.ntiles <= c->stamp_cap) {
+        a.stamps = c->stamp_buf;
+        c->stamp_n = (int64_t)a.mtiles * a.ntiles;
+    }
     pf.begin(name);
     HIP_TRY(c, launch_conv(a, tile, cw.taps, false, c->stream));
     pf.end();
@@ -684,6 +692,7 @@ void hctr_destroy(hctr_ctx* c) {
     for (auto& w : c->ws_cache) free_pool(w.allocs);
     free_pool(c->wallocs);
     free_pool(c->beam_allocs);
+    if (c->stamp_buf) (void)hipFree(c->stamp_buf);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1122,6 +1131,25 @@ int hctr_resize_lines(hctr_ctx* c, const uint8_t* packed_src, int64_t packed_byt
     if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
     free_pool(tmp);
     return rc;
+}
+
+int64_t hctr_debug_stamps(hctr_ctx* c, const char* layer, uint64_t* out, int64_t cap_wgs) {
+    if (!c || cap_wgs < 0) return HCTR_ERR_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return fail(c, HCTR_ERR_HIP, "hipSetDevice");
+    if (layer) {                                  // arm: later forwards stamp this layer's workgroups
+        if (c->stamp_buf) { (void)hipFree(c->stamp_buf); c->stamp_buf = nullptr; }
+        c->stamp_layer = layer;
+        c->stamp_cap = cap_wgs;
+        c->stamp_n = 0;
+        if (cap_wgs > 0 && hipMalloc((void**)&c->stamp_buf, (size_t)cap_wgs * 64) != hipSuccess)
+            return fail(c, HCTR_ERR_NOMEM, "stamp buffer");
+        return 0;
+    }
+    if (!out || !c->stamp_buf) return fail(c, HCTR_ERR_STATE, "stamping not armed");
+    const int64_t n = std::min(c->stamp_n, cap_wgs);
+    if (hipMemcpy(out, c->stamp_buf, (size_t)n * 64, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(c, HCTR_ERR_HIP, "stamp copy");
+    return n;
 }
 
 int64_t hctr_debug_activation(hctr_ctx* c, const char* name, float* out, int64_t cap, int* Cout, int* Hout) {

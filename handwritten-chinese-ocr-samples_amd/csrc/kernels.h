@@ -42,6 +42,7 @@ struct ConvArgs {
     int32_t* amax_idx;
     int split;              // f16x3 mode: activations are [hi | lo | hi] fp16 planes of Cout channels each
                             // (input side: Cin already counts the tripled channels)
+    unsigned long long* stamps;   // diagnostic build only (hctr_debug_stamps): 8 x u64 per workgroup, else NULL
     int dbg;                // timing experiments only (HCTR_DBG): 1 = DMA from fixed hot addresses, 2 = no DMA in the loop
 };
 

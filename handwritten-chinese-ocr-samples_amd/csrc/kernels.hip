@@ -27,6 +27,12 @@ __device__ __forceinline__ void glds16_asm(const char* gsrc, char* lds_dst) {
                  : "memory");
 }
 
+// lane permutation inside a row of 16 lanes on the VALU data path (v_mov_b32_dpp)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 // Same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (no 64-bit VALU address).
 __device__ __forceinline__ void glds16_asm_s(const char* sbase, uint32_t voff, char* lds_dst) {
     const uint32_t lds = (uint32_t)(uintptr_t)((lptr_t)lds_dst);
@@ -197,10 +203,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float s = (acc[j][0][i] + acc[j][1][i]) + (acc[j][2][i] + acc[j][3][i]);
-                s += __shfl_xor(s, 1);
-                s += __shfl_xor(s, 2);
-                s += __shfl_xor(s, 4);
-                s += __shfl_xor(s, 8);
+                // butterfly over the 16 pixel columns of a lane row on the VALU (DPP), not through ds_bpermute:
+                // pairs (c, c^1), (c, c^2), then the mirrored lane of the other quad / other half, which holds
+                // the same partial sum the xor-4 / xor-8 partner would - bitwise the xor butterfly's result
+                s += dpp_f32<0xB1>(s);            // quad_perm [1,0,3,2]
+                s += dpp_f32<0x4E>(s);            // quad_perm [2,3,0,1]
+                s += dpp_f32<0x141>(s);           // row_half_mirror
+                s += dpp_f32<0x140>(s);           // row_mirror
                 if (c == 0) red[wm * BN + wn * WC + q * 8 + co(j) + i] = s;
             }
         __syncthreads();
@@ -676,7 +685,11 @@ constexpr int kHalo4Lds = 2 * 16384 + kHaloBytes;          // 78848
 
 // GEOM 0: 16 rows x 16 columns (halo 18 x 18, row stride 20); GEOM 1: 8 rows x 32 columns for the
 // H = 8 stage (halo 10 x 34, row stride 36). Both strides are 4 (mod 8) and both halos are 360 rows.
-template <int GEOM, bool SPLIT, bool PERSIST>
+// STAMP: diagnostic instance (hctr_debug_stamps). Thread 0 of every workgroup writes wall-clock stamps
+// (s_memrealtime, 100 MHz) of its phases plus its hardware placement to a buffer no other code reads:
+//   [0] entry  [1] prologue DMA issued  [2] first operands landed (extra wait + barrier, stamp build only)
+//   [3] K loop done  [4] epilogue done (stores issued)  [5] stores drained  [6] HW_ID  [7] XCC_ID
+template <int GEOM, bool SPLIT, bool PERSIST, bool STAMP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a) {
     constexpr int WN = 1, WM = 4, JT = 8, BN = 128;
     constexpr int TR = GEOM ? 8 : 16, TC = GEOM ? 32 : 16;       // tile rows / columns
@@ -684,6 +697,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     static_assert((TR + 2) * S * 128 == kHaloBytes, "halo footprint");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
+    auto stamp = [&](int i) {
+        if (STAMP && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv;
@@ -776,6 +793,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             stage_halo(cur.xb, 0);
             stage_weights(cur.wb, 0, 0, 0);
             first = false;
+            if (STAMP) {
+                stamp(1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                stamp(2);
+            }
         }
 
         f32x4 acc[JT][4];
@@ -822,14 +845,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 read_a(1, ar[1]);
                 __builtin_amdgcn_sched_barrier(0);
                 {   // the next K step's weights into the other buffer; on a tile's last step that is the
-                    // next tile's first step (persistent), else a harmless re-stage into the idle buffer.
-                    // Branch-free on purpose: a branch here makes hipcc drain lgkmcnt(0) at the merge point.
+                    // next tile's first step (persistent variant only)
                     const bool more = k + 1 < nk;
                     const bool wrap = tap == 8;
-                    const int tap1 = more ? (wrap ? 0 : tap + 1) : (has_next ? 0 : tap);
-                    const int kc1 = more ? (wrap ? kc + 1 : kc) : (has_next ? 0 : kc);
-                    const char* wsrc = (more || !has_next) ? cur.wb : nwb;
-                    stage_weights(wsrc, kc1, tap1, (kbase + k + 1) & 1);
+                    const int tap1 = more ? (wrap ? 0 : tap + 1) : 0;
+                    const int kc1 = more ? (wrap ? kc + 1 : kc) : 0;
+                    const char* wsrc = more ? cur.wb : nwb;
+                    // nothing to stage on the very last step: no DMA is then in flight when the epilogue
+                    // starts, so the workgroup can retire without waiting for its output stores
+                    if (more || has_next) stage_weights(wsrc, kc1, tap1, (kbase + k + 1) & 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -860,6 +884,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             }
         }
         // the epilogue's scratch (SE partial sums) lives after the DMA buffers, so DMA may stay in flight
+        stamp(3);
         if (a.dbg & 128) {       // dbg 128: timing experiment without the epilogue (keeps the MFMAs alive)
             float t = 0.f;
 #pragma unroll
@@ -881,7 +906,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         tidx += nloc;
         cur = tile_at(tidx);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last (redundant) weight DMA has landed
+    if (a.dbg & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (K loop skipped: the prologue DMA is still in flight)
+    if (STAMP) {
+        stamp(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(5);
+        if (tid == 0) {
+            a.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+            a.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+        }
+    }
 }
 
 constexpr int kHalo4LdsTotal = kHalo4Lds + 4 * 128 * 4;   // + [WM][BN] floats of epilogue scratch
@@ -913,6 +947,14 @@ static hipError_t launch_conv_halo4_tp(const ConvArgs& a0, hipStream_t s) {
 }
 template <int GEOM, bool SPLIT>
 static hipError_t launch_conv_halo4_t(const ConvArgs& a, hipStream_t s) {
+    if (a.stamps != nullptr && !SPLIT) {
+        static bool done[64] = {};
+        hipError_t e0 = raise_lds_limit((const void*)conv3x3_halo4_kernel<GEOM, false, false, true>, kHalo4LdsTotal, done);
+        if (e0 != hipSuccess) return e0;
+        hipLaunchKernelGGL((conv3x3_halo4_kernel<GEOM, false, false, true>), dim3(a.mtiles * a.ntiles), dim3(256),
+                           kHalo4LdsTotal, s, a);
+        return hipGetLastError();
+    }
     // persistent tiles measured 6-8 % SLOWER on every layer (r01): kept for A/B only
     static const bool persist = [] { const char* e = getenv("HCTR_PERSIST"); return e ? atoi(e) != 0 : false; }();
     return persist ? launch_conv_halo4_tp<GEOM, SPLIT, true>(a, s) : launch_conv_halo4_tp<GEOM, SPLIT, false>(a, s);

@@ -195,6 +195,13 @@ int hctr_resize_lines(hctr_ctx* ctx, const uint8_t* packed_src, int64_t packed_b
  * Returns the number of layers recorded (or a negative status). Enabled by hctr_set_profiling. */
 int hctr_set_profiling(hctr_ctx* ctx, int enabled);
 int hctr_last_profile(hctr_ctx* ctx, char* names_buf, int cap, float* ms, int max_n);
+/* Diagnostic build of the 3x3 conv kernel: with layer != NULL, arms time-stamping of that layer's
+ * workgroups (a separate kernel instance; results of the forward are unchanged) for up to cap_wgs
+ * workgroups and returns 0. With layer == NULL copies the last forward's stamps to out[n][8]
+ * (u64: entry, prologue issued, operands landed, K loop done, epilogue done, stores drained - 100 MHz
+ * ticks - then HW_ID and XCC_ID registers) and returns n. tools/gpu_stamps.py is the consumer. */
+int64_t hctr_debug_stamps(hctr_ctx* ctx, const char* layer, uint64_t* out, int64_t cap_wgs);
+
 /* Debug taps for bisecting parity: copy an intermediate activation of the last forward to the host
  * as float32 NCHW [B][C][H][W]. name: "stage0".."stage4", "conv0_1". Returns element count or <0. */
 int64_t hctr_debug_activation(hctr_ctx* ctx, const char* name, float* out, int64_t cap,
