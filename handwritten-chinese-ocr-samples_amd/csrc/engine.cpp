@@ -1141,13 +1141,13 @@ int64_t hctr_debug_stamps(hctr_ctx* c, const char* layer, uint64_t* out, int64_t
         c->stamp_layer = layer;
         c->stamp_cap = cap_wgs;
         c->stamp_n = 0;
-        if (cap_wgs > 0 && hipMalloc((void**)&c->stamp_buf, (size_t)cap_wgs * 64) != hipSuccess)
+        if (cap_wgs > 0 && hipMalloc((void**)&c->stamp_buf, (size_t)cap_wgs * 128) != hipSuccess)
             return fail(c, HCTR_ERR_NOMEM, "stamp buffer");
         return 0;
     }
     if (!out || !c->stamp_buf) return fail(c, HCTR_ERR_STATE, "stamping not armed");
     const int64_t n = std::min(c->stamp_n, cap_wgs);
-    if (hipMemcpy(out, c->stamp_buf, (size_t)n * 64, hipMemcpyDeviceToHost) != hipSuccess)
+    if (hipMemcpy(out, c->stamp_buf, (size_t)n * 128, hipMemcpyDeviceToHost) != hipSuccess)
         return fail(c, HCTR_ERR_HIP, "stamp copy");
     return n;
 }

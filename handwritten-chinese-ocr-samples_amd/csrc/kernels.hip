@@ -10,6 +10,9 @@ namespace hctr {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const void __attribute__((address_space(1))) * gptr_t;
 typedef void __attribute__((address_space(3))) * lptr_t;
 
@@ -49,10 +52,21 @@ __device__ __forceinline__ void glds16_asm_s(const char* sbase, uint32_t voff, c
 // lane (q, c): for cout block cb (64 couts) the lane owns couts (jj>>1)*32 + q*8 + (jj&1)*4 + i (jj = j & 3),
 // i.e. two runs of 8 consecutive couts, of pixel column c and pixel repeat n.
 // -------------------------------------------------------------------------------------------
-template <int WN, int WM, int JT, bool LINEAR, bool SPLIT, bool PRIVATE_RED = false>
+// cout offset of accumulator tile j inside a wave's cout range (see conv_epilogue)
+__device__ __forceinline__ constexpr int acc_cout_offset(int j) { return (j >> 2) * 64 + ((j >> 1) & 1) * 32 + (j & 1) * 4; }
+
+template <int WN, int WM, int JT, bool LINEAR, bool SPLIT, bool PRIVATE_RED = false, bool BIAS_DONE = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT][4], char* smem, int tid, int lane,
                                               int wn, int wm, int n0, int mt, int img, int th, int tw, int hbase,
-                                              int w0) {
+                                              int w0, unsigned long long* st = nullptr) {
+    // diagnostic instance only: st = this workgroup's stamp slots 8.. (after bias, residual, rounding, SE sums)
+    auto estamp = [&](int i) {
+        if (st != nullptr) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (tid == 0) st[i] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     constexpr int WC = JT * 16;
     constexpr int BN = WN * WC, BM = WM * 64;
     const int q = lane >> 4;
@@ -61,17 +75,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
     // cout offset of accumulator tile j (cb = j>>2 the 64-cout block, jj = j&3): a lane owns two runs of 8
     // consecutive couts per block, q*8.. (jj 0,1) and 32+q*8.. (jj 2,3), so the four lanes of a pixel write
     // 64 contiguous bytes per store instruction (half a cache line without holes).
-    auto co = [](int j) { return (j >> 2) * 64 + ((j >> 1) & 1) * 32 + (j & 1) * 4; };
+    auto co = [](int j) { return acc_cout_offset(j); };
 
+    if (!BIAS_DONE) {                   // (the halo4 kernel starts its accumulators at the bias instead)
 #pragma unroll
-    for (int j = 0; j < JT; ++j) {
-        const f32x4 b4 = *(const f32x4*)(a.bias + cw0 + co(j));
+        for (int j = 0; j < JT; ++j) {
+            const f32x4 b4 = *(const f32x4*)(a.bias + cw0 + co(j));
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][n][i] += b4[i];
+                for (int i = 0; i < 4; ++i) acc[j][n][i] += b4[i];
+        }
     }
 
+    estamp(8);
     if (LINEAR && a.amax_idx != nullptr) {
         // fused greedy argmax: classes rise with (j, i) for a lane and with q, wn, nt beyond it, so a strict
         // '>' keeps the first maximum inside a lane and the (value, class) merge keeps it across lanes.
@@ -170,7 +187,91 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
         }
     }
 
-    // ReLU, column mask, fp16 rounding (in place: acc now holds exactly the values that are stored)
+    estamp(9);
+    if (!SPLIT) {
+        // One rounding to fp16 (v_cvt_pk_f16_f32, RNE), then ReLU and the column mask on PACKED halves:
+        // rounding is monotonic and keeps the sign, so relu(round(v)) == round(relu(v)). P holds exactly the
+        // stored values; about 2 VALU ops per value instead of 7.
+        const _Float16 lo1 = a.relu ? (_Float16)0.f : (_Float16)(-INFINITY);
+        const f16x2 lo2 = {lo1, lo1};
+        const uint32_t keep = wvalid ? 0xffffffffu : 0u;
+        uint32_t P[JT][4][2];
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                f32x4 v = acc[j][n];
+                if (a.pool) {                                    // (2,1) max-pool -> even n; odd n unused
+                    const f32x4 u = acc[j][n | 1];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[j][n & ~1][i], u[i]);
+                }
+                f16x2 h0 = __builtin_convertvector((f32x2){v[0], v[1]}, f16x2);
+                f16x2 h1 = __builtin_convertvector((f32x2){v[2], v[3]}, f16x2);
+                h0 = __builtin_elementwise_max(h0, lo2);
+                h1 = __builtin_elementwise_max(h1, lo2);
+                P[j][n][0] = __builtin_bit_cast(uint32_t, h0) & keep;
+                P[j][n][1] = __builtin_bit_cast(uint32_t, h1) & keep;
+            }
+        estamp(10);
+        if (a.se_part != nullptr) {
+            // per-(image, channel) sums of the stored values over this block's pixels, fixed reduction
+            // order (deterministic: lane tree -> LDS -> one partial row per block; no float atomics).
+            if (!PRIVATE_RED) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a trailing LDS-DMA (if any) has landed
+                __syncthreads();                   // main-loop LDS no longer needed
+            }
+            float* red = (float*)smem;             // [WM][BN]
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t[4];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        t[n] = (float)__builtin_bit_cast(f16x2, P[j][n][i >> 1])[i & 1];
+                    float sum = (t[0] + t[1]) + (t[2] + t[3]);
+                    sum += dpp_f32<0xB1>(sum);            // quad_perm [1,0,3,2]
+                    sum += dpp_f32<0x4E>(sum);            // quad_perm [2,3,0,1]
+                    sum += dpp_f32<0x141>(sum);           // row_half_mirror
+                    sum += dpp_f32<0x140>(sum);           // row_mirror
+                    if (c == 0) red[wm * BN + wn * WC + q * 8 + co(j) + i] = sum;
+                }
+            __syncthreads();
+            if (tid < BN) {
+                float sum = 0.f;
+#pragma unroll
+                for (int m = 0; m < WM; ++m) sum += red[m * BN + tid];
+                const int64_t tile = (int64_t)img * (a.tilesH * a.tilesW) + th * a.tilesW + tw;
+                if (n0 + tid < a.Cout) a.se_part[tile * a.Cout + n0 + tid] = sum;
+            }
+        }
+        estamp(11);
+        if (a.dbg & 256) {           // dbg 256: timing experiment without the output stores
+            uint32_t t = 0;
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) t += P[j][n][0] ^ P[j][n][1];
+            if (t == 0x12345678u) out[0] = (half_t)1.f;
+        } else if (w < a.out_wlimit) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (a.pool && (n & 1)) continue;
+                const int ho = a.pool ? ((hbase + n) >> 1) : (hbase + n);
+                half_t* o = out + pix0 + (int64_t)ho * a.out_sh;
+#pragma unroll
+                for (int cb = 0; cb < JT / 4; ++cb) {
+                    const int j0 = cb * 4;
+                    *(u32x4*)(o + cb * 64) = (u32x4){P[j0][n][0], P[j0][n][1], P[j0 + 1][n][0], P[j0 + 1][n][1]};
+                    *(u32x4*)(o + cb * 64 + 32) =
+                        (u32x4){P[j0 + 2][n][0], P[j0 + 2][n][1], P[j0 + 3][n][0], P[j0 + 3][n][1]};
+                }
+            }
+        }
+        return;
+    }
+    // f16x3 (SPLIT) tail. ReLU, column mask, fp16 rounding (in place: acc holds exactly what the planes add up to)
 #pragma unroll
     for (int j = 0; j < JT; ++j)
 #pragma unroll
@@ -190,6 +291,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
                 acc[j][n][i] = v;
             }
 
+    estamp(10);
     if (a.se_part != nullptr) {
         // per-(image, channel) sums of the stored values over this block's pixels, fixed reduction
         // order (deterministic: lane tree -> LDS -> one partial row per block; no float atomics).
@@ -222,6 +324,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
         }
     }
 
+    estamp(11);
     if (a.dbg & 256) {           // dbg 256: timing experiment without the output stores
         float t = 0.f;
 #pragma unroll
@@ -689,6 +792,7 @@ constexpr int kHalo4Lds = 2 * 16384 + kHaloBytes;          // 78848
 // (s_memrealtime, 100 MHz) of its phases plus its hardware placement to a buffer no other code reads:
 //   [0] entry  [1] prologue DMA issued  [2] first operands landed (extra wait + barrier, stamp build only)
 //   [3] K loop done  [4] epilogue done (stores issued)  [5] stores drained  [6] HW_ID  [7] XCC_ID
+//   [8..11] inside the epilogue: bias added, residual applied, values rounded, SE sums written
 template <int GEOM, bool SPLIT, bool PERSIST, bool STAMP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a) {
     constexpr int WN = 1, WM = 4, JT = 8, BN = 128;
@@ -698,7 +802,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     auto stamp = [&](int i) {
-        if (STAMP && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+        if (STAMP && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + i] = __builtin_amdgcn_s_memrealtime();
     };
     stamp(0);
     const int lane = tid & 63;
@@ -801,11 +905,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             }
         }
 
+        // accumulators start at the folded-BN bias (its load hides behind the first operands' DMA)
         f32x4 acc[JT][4];
 #pragma unroll
-        for (int j = 0; j < JT; ++j)
+        for (int j = 0; j < JT; ++j) {
+            const f32x4 b4 = *(const f32x4*)(a.bias + cur.n0 + q * 8 + acc_cout_offset(j));
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < 4; ++n) acc[j][n] = b4;
+        }
 
         // Retire every scalar (kernarg) load before the loop. A load still pending at the loop header keeps
         // hipcc's counter model "dirty" on every iteration (scalar loads return out of order), and it then
@@ -898,8 +1005,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             const int t2 = cur.mt / a.tilesW;
             const int th = t2 % a.tilesH;
             const int img = t2 / a.tilesH;
-            conv_epilogue<WN, WM, JT, false, SPLIT, true>(a, acc, smem + kHalo4Lds, tid, lane, 0, wm, cur.n0, cur.mt,
-                                                          img, th, tw, th * TR + wrow, tw * TC + wcol);
+            conv_epilogue<WN, WM, JT, false, SPLIT, true, true>(a, acc, smem + kHalo4Lds, tid, lane, 0, wm, cur.n0, cur.mt,
+                                                          img, th, tw, th * TR + wrow, tw * TC + wcol,
+                                                          STAMP ? a.stamps + (size_t)blockIdx.x * 16 : nullptr);
         }
         if (!has_next) break;
         kbase += nk;
@@ -912,8 +1020,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(5);
         if (tid == 0) {
-            a.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
-            a.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+            a.stamps[(size_t)blockIdx.x * 16 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+            a.stamps[(size_t)blockIdx.x * 16 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
         }
     }
 }

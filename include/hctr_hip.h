@@ -197,9 +197,9 @@ int hctr_set_profiling(hctr_ctx* ctx, int enabled);
 int hctr_last_profile(hctr_ctx* ctx, char* names_buf, int cap, float* ms, int max_n);
 /* Diagnostic build of the 3x3 conv kernel: with layer != NULL, arms time-stamping of that layer's
  * workgroups (a separate kernel instance; results of the forward are unchanged) for up to cap_wgs
- * workgroups and returns 0. With layer == NULL copies the last forward's stamps to out[n][8]
+ * workgroups and returns 0. With layer == NULL copies the last forward's stamps to out[n][16]
  * (u64: entry, prologue issued, operands landed, K loop done, epilogue done, stores drained - 100 MHz
- * ticks - then HW_ID and XCC_ID registers) and returns n. tools/gpu_stamps.py is the consumer. */
+ * ticks - HW_ID and XCC_ID registers, then four stamps inside the epilogue) and returns n. tools/gpu_stamps.py is the consumer. */
 int64_t hctr_debug_stamps(hctr_ctx* ctx, const char* layer, uint64_t* out, int64_t cap_wgs);
 
 /* Debug taps for bisecting parity: copy an intermediate activation of the last forward to the host

@@ -30,7 +30,7 @@ model.greedy(imgs)                                   # warm-up (workspace, clock
 _lib.check(int(lib.hctr_debug_stamps(model._ctx, layer.encode(), None, cap)), model._ctx)
 model.greedy(imgs)
 model.greedy(imgs)
-out = np.zeros((cap, 8), np.uint64)
+out = np.zeros((cap, 16), np.uint64)
 n = int(lib.hctr_debug_stamps(model._ctx, None, out.ctypes.data_as(ctypes.c_void_p), cap))
 if n <= 0:
     raise SystemExit("no stamps recorded for layer %r (n=%d)" % (layer, n))
@@ -41,6 +41,11 @@ names = ["entry->prologue issued", "prologue issued->operands landed", "operands
 print("layer %s: %d workgroups, span %.1f us" % (layer, n, t[:, 5].max() - t[:, 0].min()))
 for i, nm in enumerate(names):
     d = t[:, i + 1] - t[:, i]
+    print("  %-36s median %7.2f us   p10 %7.2f   p90 %7.2f" % (nm, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+e = s[:, [3, 8, 9, 10, 11, 4]] * 10e-3
+for i, nm in enumerate(["  epilogue: bias loaded + added", "  epilogue: residual / SE scale", "  epilogue: relu, pool, rounding",
+                        "  epilogue: SE partial sums", "  epilogue: output stores issued"]):
+    d = e[:, i + 1] - e[:, i]
     print("  %-36s median %7.2f us   p10 %7.2f   p90 %7.2f" % (nm, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
 life = t[:, 5] - t[:, 0]
 print("  %-36s median %7.2f us   p10 %7.2f   p90 %7.2f" % ("workgroup lifetime", np.median(life), np.percentile(life, 10), np.percentile(life, 90)))
