@@ -139,7 +139,7 @@ def main():
     # gfx950 as MI355X_MICROARCH.md prescribes), summarised into profiles/per_layer_latest.json.
     traffic, traffic_src = None, None
     pj = os.path.join(ROOT, "profiles", "per_layer_latest.json")
-    if os.path.isfile(pj) and B == B_PER_GPU and W == W_LINE:
+    if os.path.isfile(pj) and B == B_PER_GPU and W == W_LINE and args.precision == "f16":   # (PMC passes ran in f16)
         with open(pj) as f:
             rows = [r for r in json.load(f) if r["layer"] in DOMINANT and r.get("fetch_gb_x2") is not None]
         if rows:

@@ -427,6 +427,12 @@ struct Prof {
     }
 };
 
+// start of an API call: forget the previous call's per-layer events (a call may run several internal passes,
+// whose entries of the same name hctr_last_profile adds up)
+inline void prof_reset(hctr_ctx* c) {
+    if (c->profiling) { c->prof.clear(); c->ev_used = 0; }
+}
+
 struct ActDesc {            // a padded NHWC activation
     half_t* p;
     int H, C;
@@ -542,7 +548,6 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
 int run_forward(hctr_ctx* c, int img_f32, bool have_widths, bool fused_argmax = false) {
     Workspace& ws = c->ws;
     Prof pf(c);
-    if (c->profiling) { c->prof.clear(); c->ev_used = 0; }
     pf.begin("stem.conv0_1");
     HIP_TRY(c, launch_stem(ws.img, img_f32, have_widths ? ws.widths : nullptr, c->stem_w, c->stem_b, ws.s0, ws.B,
                            ws.W, ws.Wa, c->split, c->stream));
@@ -776,14 +781,21 @@ int hctr_last_profile(hctr_ctx* c, char* names_buf, int cap, float* ms, int max_
     if (!c) return HCTR_ERR_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     std::string names;
+    std::vector<std::string> order;
     int n = 0;
     for (auto& pe : c->prof) {
-        if (n >= max_n) break;
         float t = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&t, pe.e0, pe.e1));
-        ms[n++] = t;
-        names += pe.name;
-        names += '\n';
+        size_t i = 0;
+        while (i < order.size() && order[i] != pe.name) ++i;      // internal passes repeat the layer names
+        if (i == order.size()) {
+            if (n >= max_n) break;
+            order.push_back(pe.name);
+            ms[n++] = 0.f;
+            names += pe.name;
+            names += '\n';
+        }
+        ms[i] += t;
     }
     if (names_buf && cap > 0) {
         strncpy(names_buf, names.c_str(), (size_t)cap - 1);
@@ -800,6 +812,7 @@ int hctr_forward_logits(hctr_ctx* c, const void* img, int img_dtype, int img_on_
     HIP_TRY(c, hipSetDevice(c->device));
     const int C = c->num_classes;
     const int nbmax = sub_batch(c, B, W);
+    prof_reset(c);
     float* dev_out = out_wbc;
     std::vector<void*> tmp;
     if (!out_on_device) {
@@ -836,6 +849,7 @@ int hctr_greedy(hctr_ctx* c, const void* img, int img_dtype, int img_on_device, 
     HIP_TRY(c, hipSetDevice(c->device));
     const int C = c->num_classes;
     const int nbmax = sub_batch(c, B, W);
+    prof_reset(c);
     for (int b0 = 0; b0 < B; b0 += nbmax) {
         const int nb = std::min(nbmax, B - b0);
         TRY(ensure_workspace(c, nb, W));
@@ -919,6 +933,7 @@ int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_d
     if (k > C) return fail(c, HCTR_ERR_ARG, "k=%d exceeds C=%d", k, C);
     const double thresh = std::log(0.001);        // utils/ctc_codec.py:128
     const int nbmax = from_img ? sub_batch(c, B, W) : B;
+    prof_reset(c);
     struct PassOut { int b0, nb; std::vector<int64_t> loff; std::vector<int32_t> ci; std::vector<float> cl; };
     std::vector<PassOut> outs;
     std::vector<int32_t> counts((size_t)W * B, 0);
