@@ -594,3 +594,36 @@ def test_device_resize_bit_exact(engine, pkg, codec):
     with pytest.raises(ValueError):
         pp.resize_lines(engine, [np.zeros((4, 4), np.float32)])
     assert pp.resize_lines(engine, [])[0].shape == (0, 128, 0)
+
+
+def test_rccl_gather_path_runs():
+    """bench.py's N>1 result gather through RCCL (backend "nccl"), with the one rank this box has: process
+    group init bound to the device, dist.gather of device tensors, barrier. (World size 2 logic: gloo CPU test.)"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_nccl_gather_check.py")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok nccl gather" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_stamped_diagnostic_instance_keeps_results(engine, pkg, synth):
+    """hctr_debug_stamps arms a separate kernel instance for one layer; the forward's results must not change
+    and the stamps must be ordered (entry <= prologue <= landed <= K loop <= epilogue <= drained)."""
+    import ctypes
+    lib = pkg._lib.load()
+    imgs = synth.make_line_images(2, 96, 23)
+    want = engine(imgs)
+    cap = 4096
+    assert int(lib.hctr_debug_stamps(engine._ctx, b"block3.1.conv2+se", None, cap)) == 0
+    try:
+        got = engine(imgs)
+        out = np.zeros((cap, 16), np.uint64)
+        n = int(lib.hctr_debug_stamps(engine._ctx, None, out.ctypes.data_as(ctypes.c_void_p), cap))
+    finally:
+        lib.hctr_debug_stamps(engine._ctx, b"", None, 0)          # disarm
+    assert np.array_equal(got, want)
+    assert n == 2 * 1 * 6 * 4                                      # images x tile rows x tile columns x cout tiles
+    t = out[:n, :6].astype(np.int64)
+    assert (np.diff(t, axis=1) >= 0).all() and (t[:, 5] - t[:, 0]).max() < 10 ** 7
