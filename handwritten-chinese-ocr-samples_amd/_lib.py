@@ -35,9 +35,24 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """Compile csrc/ into libhctr_hip.so (cross-compiles without a GPU)."""
+    """Compile csrc/ into libhctr_hip.so (cross-compiles without a GPU). Safe to call from several
+    processes at once (one rank per GPU): an exclusive file lock serialises the build, later callers find
+    the library fresh, and the link goes to a temporary name that is renamed into place."""
     if not force and not _stale():
         return LIB_PATH
+    import fcntl
+    os.makedirs(os.path.join(PKG_DIR, "build"), exist_ok=True)
+    with open(os.path.join(PKG_DIR, "build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB_PATH
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.isfile(hipcc):
         hipcc = "hipcc"
@@ -51,10 +66,12 @@ def build(force=False, verbose=False):
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-lpthread"]
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
