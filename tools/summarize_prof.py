@@ -39,16 +39,32 @@ def main(d):
                 if r["Counter_Name"] == ctr:
                     acc[(short(r["Kernel_Name"]), int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
         pmc[kind] = acc
+    # MFMA pipe utilisation (own PMC pass): SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 SIMDs,
+    # GRBM_GUI_ACTIVE sums the active cycles of the 8 XCDs -> busy / (128 * gui_active); clock = gui / 8 / time
+    mf = collections.defaultdict(lambda: collections.defaultdict(list))
+    files = glob.glob(os.path.join(d, "pmc_mfma", "*", "*_counter_collection.csv"))
+    if files:
+        for r in csv.DictReader(open(files[0])):
+            k = (short(r["Kernel_Name"]), int(r["Grid_Size"]))
+            mf[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            mf[k]["_t_" + r["Counter_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     total = sum(sum(v) for v in dur.values())
-    print("| kernel | grid (threads) | launches | avg ms | % time | FETCH_SIZE/launch (GB raw / x2) | WRITE_SIZE/launch (GB) |")
-    print("|---|---|---|---|---|---|---|")
+    print("| kernel | grid (threads) | launches | avg ms | % time | FETCH_SIZE/launch (GB raw / x2) | WRITE_SIZE/launch (GB) | MFMA pipe busy | clock GHz |")
+    print("|---|---|---|---|---|---|---|---|---|")
     for key, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         f = pmc["fetch"].get(key)
         w = pmc["write"].get(key)
         fs = "%.3f / %.3f" % (sum(f) / len(f) * 1024 / 1e9, 2 * sum(f) / len(f) * 1024 / 1e9) if f else "-"
         wsz = "%.3f" % (sum(w) / len(w) * 1024 / 1e9) if w else "-"
-        print("| %s | %d | %d | %.3f | %.1f | %s | %s |" % (key[0], key[1], len(v), sum(v) / len(v) / 1e6,
-                                                        100.0 * sum(v) / total, fs, wsz))
+        m = mf.get(key)
+        util, clk = "-", "-"
+        if m and m.get("GRBM_GUI_ACTIVE") and sum(m["GRBM_GUI_ACTIVE"]) > 0:
+            gui = sum(m["GRBM_GUI_ACTIVE"])
+            if m.get("SQ_VALU_MFMA_BUSY_CYCLES") and sum(m["SQ_VALU_MFMA_BUSY_CYCLES"]) > 0:
+                util = "%.0f %%" % (100.0 * sum(m["SQ_VALU_MFMA_BUSY_CYCLES"]) / (128.0 * gui))
+            clk = "%.2f" % (gui / 8.0 / sum(m["_t_GRBM_GUI_ACTIVE"]))
+        print("| %s | %d | %d | %.3f | %.1f | %s | %s | %s | %s |" % (key[0], key[1], len(v), sum(v) / len(v) / 1e6,
+                                                                100.0 * sum(v) / total, fs, wsz, util, clk))
 
 
 def per_layer(d):
