@@ -8,6 +8,7 @@ TAG=${1:-r01}
 shift || true
 EXTRA="$@"
 OUT=$PWD/gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}

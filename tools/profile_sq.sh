@@ -4,6 +4,7 @@
 set -e
 TAG=${1:-r01}
 OUT=$PWD/gpurun_out/sq_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
