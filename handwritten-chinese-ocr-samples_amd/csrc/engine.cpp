@@ -112,6 +112,7 @@ struct hctr_ctx {
     std::string stamp_layer;         // hctr_debug_stamps: layer whose workgroups are time-stamped (diagnostic)
     unsigned long long* stamp_buf = nullptr;
     int64_t stamp_cap = 0, stamp_n = 0;
+    bool fuse_ds = true;             // 1x1 downsample inside conv2's K loop (HCTR_FUSE_DS=0: own launch + residual)
     bool fuse_argmax = true;         // greedy: argmax in the head GEMM's epilogue (HCTR_FUSE_ARGMAX=0: separate pass)
     // profiling
     bool profiling = false;
@@ -451,7 +452,7 @@ ConvTile pick_tile(const hctr_ctx* c, const ConvW& cw, int H) {
 
 int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc in, half_t* out, int outH,
              bool relu, bool pool, float* se_part, bool to_head, const float* se_scale = nullptr,
-             const half_t* resid = nullptr) {
+             const half_t* resid = nullptr, const ConvW* ds = nullptr, const half_t* ds_in = nullptr) {
     const Workspace& ws = c->ws;
     ConvArgs a{};
     a.x = in.p; a.w = cw.w; a.bias = cw.bias; a.y = out; a.se_part = se_part;
@@ -481,6 +482,13 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
         a.out_wlimit = a.tilesW * cols;
     }
     a.relu = relu; a.pool = pool;
+    if (ds) {                 // fused 1x1 downsample of the block input (same H, W, Wa; ds->cin channels)
+        if (tile != TILE_HALO4 || c->split || !se_scale || resid || ds->cin % kBK != 0 || ds->coutPad != cw.coutPad)
+            return fail(c, HCTR_ERR_STATE, "conv %s: downsample fusion not applicable", name);
+        a.ds_x = ds_in; a.ds_w = ds->w; a.ds_bias = ds->bias; a.ds_cin = ds->cin;
+        a.ds_in_sh = ws.Wa * ds->cin;
+        a.ds_in_sb = (int64_t)(in.H + 2) * ws.Wa * ds->cin;
+    }
     a.mtiles = ws.B * a.tilesH * a.tilesW;
     a.ntiles = cw.coutPad / conv_tile_couts(tile);
     if (c->stamp_buf && c->stamp_layer == name && (tile == TILE_HALO4 || tile == TILE_HALO4_8x32) &&
@@ -508,7 +516,11 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
     };
     const float inv_hw = 1.0f / ((float)H * (float)ws.W);
     const half_t* res = in.p;
-    if (bw.has_ds) {
+    // first block of stages 1-3: the 1x1 downsample branch runs inside conv2's K loop (kernels.hip DSFUSE) when
+    // conv2 is on the default halo kernel; otherwise (A/B paths, f16x3) as its own launch writing the residual r
+    const bool fuse_ds = bw.has_ds && c->fuse_ds && c->fuse_se && !c->split && bw.ds.cin % kBK == 0 &&
+                         pick_tile(c, bw.conv2, H) == TILE_HALO4;
+    if (bw.has_ds && !fuse_ds) {
         TRY(run_conv(c, pf, (name + ".downsample").c_str(), bw.ds, in, r, H, false, false, nullptr, false));
         res = r;
     }
@@ -525,8 +537,12 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
         pf.begin((name + ".se_fc").c_str());
         HIP_TRY(c, launch_se_fc(ws.se_mean, 1, bw.se.w1, bw.se.w2, ws.se_scale, ws.B, planes, 1.0f, c->stream));
         pf.end();
-        TRY(run_conv(c, pf, (name + ".conv2+se").c_str(), bw.conv2, ActDesc{t, H, planes}, o, H, true, false, nullptr,
-                     false, ws.se_scale, res));
+        if (fuse_ds)
+            TRY(run_conv(c, pf, (name + ".conv2+se+ds").c_str(), bw.conv2, ActDesc{t, H, planes}, o, H, true, false,
+                         nullptr, false, ws.se_scale, nullptr, &bw.ds, in.p));
+        else
+            TRY(run_conv(c, pf, (name + ".conv2+se").c_str(), bw.conv2, ActDesc{t, H, planes}, o, H, true, false,
+                         nullptr, false, ws.se_scale, res));
         return HCTR_OK;
     }
     TRY(run_conv(c, pf, (name + ".conv1").c_str(), bw.conv1, in, t, H, true, false, nullptr, false));
@@ -678,6 +694,7 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
     if (const char* pr = getenv("HCTR_PRECISION")) c->split = std::string(pr) == "f16x3";
     if (const char* fs = getenv("HCTR_FUSE_SE")) c->fuse_se = atoi(fs) != 0;
     if (const char* fa = getenv("HCTR_FUSE_ARGMAX")) c->fuse_argmax = atoi(fa) != 0;
+    if (const char* fd = getenv("HCTR_FUSE_DS")) c->fuse_ds = atoi(fd) != 0;
     if (const char* wb = getenv("HCTR_WS_BUDGET_GB")) {
         const long long v = atoll(wb);
         if (v > 0) c->ws_budget = (size_t)v << 30;

@@ -42,6 +42,15 @@ struct ConvArgs {
     int32_t* amax_idx;
     int split;              // f16x3 mode: activations are [hi | lo | hi] fp16 planes of Cout channels each
                             // (input side: Cin already counts the tripled channels)
+    // fused 1x1 downsample of a block's input (first block of stages 1-3): the halo4 kernel first accumulates
+    // ds_w * ds_x (centre tap, ds_cin channels, same H/W/Wa geometry as x), turns it into the residual term and
+    // continues with the 3x3 taps; resid must then be NULL and se_scale set. NULL = not used.
+    const half_t* ds_x;
+    const half_t* ds_w;       // [1][CoutPad][ds_cin], rows permuted like w
+    const float* ds_bias;     // folded BN of the downsample
+    int ds_cin;
+    int ds_in_sh;             // elements per image row of ds_x
+    int64_t ds_in_sb;         // elements per image of ds_x
     unsigned long long* stamps;   // diagnostic build only (hctr_debug_stamps): 8 x u64 per workgroup, else NULL
     int dbg;                // timing experiments only (HCTR_DBG): 1 = DMA from fixed hot addresses, 2 = no DMA in the loop
 };

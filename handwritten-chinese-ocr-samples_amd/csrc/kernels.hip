@@ -55,7 +55,12 @@ __device__ __forceinline__ void glds16_asm_s(const char* sbase, uint32_t voff, c
 // cout offset of accumulator tile j inside a wave's cout range (see conv_epilogue)
 __device__ __forceinline__ constexpr int acc_cout_offset(int j) { return (j >> 2) * 64 + ((j >> 1) & 1) * 32 + (j & 1) * 4; }
 
-template <int WN, int WM, int JT, bool LINEAR, bool SPLIT, bool PRIVATE_RED = false, bool BIAS_DONE = false>
+// SE scales below this are treated as this value on both sides of the downsample fusion (the accumulators hold
+// residual / max(s, floor) and are multiplied by max(s, floor)): keeps the quotient finite for a saturated sigmoid
+constexpr float kSeScaleFloor = 1e-12f;
+
+template <int WN, int WM, int JT, bool LINEAR, bool SPLIT, bool PRIVATE_RED = false, bool BIAS_DONE = false,
+          bool RESID_IN_ACC = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT][4], char* smem, int tid, int lane,
                                               int wn, int wm, int n0, int mt, int img, int th, int tw, int hbase,
                                               int w0, unsigned long long* st = nullptr) {
@@ -158,6 +163,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
                         acc[cb * 4 + (e >> 2)][n][e & 3] = fmaf(acc[cb * 4 + (e >> 2)][n][e & 3], sv, rv);
                     }
                 }
+        }
+    } else if (RESID_IN_ACC) {
+        // fused downsample (halo4 DSFUSE instance): the residual already sits in the accumulators as r / s
+        // (compile-time branch: as a third runtime branch it made hipcc spill in every instance of this epilogue)
+        const float* sc = a.se_scale + (int64_t)img * a.Cout + cw0;
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            const f32x4 s4 = *(const f32x4*)(sc + co(j));
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][n][i] *= fmaxf(s4[i], kSeScaleFloor);
         }
     } else if (a.se_scale != nullptr) {
         const float* sc = a.se_scale + (int64_t)img * a.Cout + cw0;
@@ -793,8 +810,13 @@ constexpr int kHalo4Lds = 2 * 16384 + kHaloBytes;          // 78848
 //   [0] entry  [1] prologue DMA issued  [2] first operands landed (extra wait + barrier, stamp build only)
 //   [3] K loop done  [4] epilogue done (stores issued)  [5] stores drained  [6] HW_ID  [7] XCC_ID
 //   [8..11] inside the epilogue: bias added, residual applied, values rounded, SE sums written
-template <int GEOM, bool SPLIT, bool PERSIST, bool STAMP = false>
+// DSFUSE: a block's 1x1 downsample branch (models/handwritten_ctr_model.py:101-108, used at :49-50,57) runs as a
+// pre-phase of conv2's K loop instead of as its own launch: acc = Wd * x over the block input's channels (centre
+// tap of x's halo), then acc <- (acc + bd) / s + b2, then the 3x3 taps of conv2 accumulate on top and the epilogue
+// multiplies by s: s * (W2*t + b2) + (Wd*x + bd). The residual is neither written nor read back (4.2 GB per launch).
+template <int GEOM, bool SPLIT, bool PERSIST, bool STAMP = false, bool DSFUSE = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a) {
+    static_assert(!DSFUSE || (!PERSIST && !SPLIT), "downsample fusion: default f16 path only");
     constexpr int WN = 1, WM = 4, JT = 8, BN = 128;
     constexpr int TR = GEOM ? 8 : 16, TC = GEOM ? 32 : 16;       // tile rows / columns
     constexpr int S = TC + 4;                                      // halo row stride in pixels
@@ -847,22 +869,54 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     const int aoff0 = c * 128 + (((0 + q) ^ (lane & 7)) << 4);
     const int aoff1 = c * 128 + (((4 + q) ^ (lane & 7)) << 4);
 
-    auto stage_weights = [&](const char* wb, int kc, int tap, int buf) {
-        const char* src = wb + ((int64_t)tap * a.CoutPad * cin + (int64_t)kc * kBK) * 2;
+    auto stage_w = [&](const char* wb, int rowcin, const uint32_t (&wo)[4], int kc, int tap, int buf) {
+        const char* src = wb + ((int64_t)tap * a.CoutPad * rowcin + (int64_t)kc * kBK) * 2;
         char* dst = smem + buf * 16384 + (wv * 4) * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16_asm_s(src, woff[i], dst + i * 1024);
+        for (int i = 0; i < 4; ++i) glds16_asm_s(src, wo[i], dst + i * 1024);
     };
+    auto stage_weights = [&](const char* wb, int kc, int tap, int buf) { stage_w(wb, cin, woff, kc, tap, buf); };
     auto stage_halo = [&](const char* xb, int kc) {
         const char* src = xb + (int64_t)kc * (kBK * 2);
 #pragma unroll
         for (int r = 0; r < 12; ++r)
             if (wv + 4 * r < kHaloPieces) glds16_asm_s(src, hoff[r], smem + 32768 + (wv + 4 * r) * 1024);
     };
+    // per-lane DMA offsets of a source tensor with `rowcin` channels and `in_sh` elements per image row
+    // (recomputed where needed - from an opaque lane id, so they are not kept alive across the epilogue)
+    auto lane_offsets = [&](int rowcin, int in_sh, uint32_t (&wo)[4], bool with_halo) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = (wv * 4 + i) * 64 + ln;
+            const int row = g >> 3, cp = (g & 7) ^ (row & 7);
+            wo[i] = (uint32_t)row * (uint32_t)rowcin * 2u + cp * 16;
+        }
+        if (!with_halo) return;
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {                          // piece wv + 4r
+            const int g = (wv + 4 * r) * 64 + ln;
+            const int row = g >> 3, cp = (g & 7) ^ (row & 7);
+            int hy = row / S, hx = row - hy * S;
+            if (hx > TC + 1) hx = TC + 1;                       // pad columns: any valid address
+            if (hy > TR + 1) hy = TR + 1;                       // pieces >= 45 are never issued
+            hoff[r] = ((uint32_t)hy * (uint32_t)in_sh + (uint32_t)hx * (uint32_t)rowcin) * 2u + cp * 16;
+        }
+    };
     const int hbuf = 32768 + wrow * (S * 128);
+    // fragment addresses of a tap inside the halo image
+    auto b_ptrs = [&](int tap, const char*& be, const char*& bo) {
+        const int tdy = tap / 3, dx = tap - tdy * 3 - 1;
+        const int u = wcol + c + 1 + dx;
+        const int v0 = u * 128 + (((q ^ (u & 7) ^ ((tdy & 1) << 2)) & 7) << 4);
+        const char* hb = smem + hbuf + tdy * (S * 128);
+        be = hb + v0;
+        bo = hb + (v0 ^ 64);
+    };
 
     Tile cur = tile_at(tidx);
-    int kbase = 0;                                  // weight-buffer parity continues across tiles
+    int kbase = 0;                                  // weight-buffer parity continues across tiles / phases
     bool first = true;
 
     for (;;) {
@@ -874,44 +928,124 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             nxb = t.xb;
             nwb = t.wb;
         }
-        if (PERSIST || first) {      // per-lane DMA offsets: recomputed per tile so they are dead in the epilogue
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-        #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int g = (wv * 4 + i) * 64 + ln;
-                const int row = g >> 3, cp = (g & 7) ^ (row & 7);
-                woff[i] = (uint32_t)row * (uint32_t)cin * 2u + cp * 16;
+        f32x4 acc[JT][4];
+        // One K step: 64 MFMAs of this wave on the weight tile at `wt` and the pixel fragments at be / bo.
+        // Rolling fragment pipeline: 8 groups of 8 MFMAs (2 A fragments x 4 B fragments); A pairs are read two
+        // groups ahead into a 3-slot ring, the second half's B fragments during group 1; `stage_next` issues the
+        // next step's weight DMA after the first reads so its issue cost overlaps their LDS latency.
+        auto mma_step = [&](const char* wt, const char* be, const char* bo, auto&& stage_next) {
+            f16x8 ar[3][2], bq[2][4];
+            auto read_a = [&](int g, f16x8 (&dst)[2]) {
+                const int ks = g >> 2, jp = g & 3;
+                const char* base = wt + (ks ? aoff1 : aoff0);
+                dst[0] = *(const f16x8*)(base + (2 * jp) * 2048);
+                dst[1] = *(const f16x8*)(base + (2 * jp + 1) * 2048);
+            };
+            auto read_b = [&](int ks, f16x8 (&dst)[4]) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    dst[n] = *(const f16x8*)((((n & 1) ^ ks) ? bo : be) + n * (S * 128));
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            read_b(0, bq[0]);
+            read_a(0, ar[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(1, ar[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_next();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int ks = g >> 2, jp = g & 3;
+                if (g + 2 < 8) read_a(g + 2, ar[(g + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g == 1) { read_b(1, bq[1]); __builtin_amdgcn_sched_barrier(0); }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[2 * jp + jj][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            ar[g % 3][jj], bq[ks][n], acc[2 * jp + jj][n], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        #pragma unroll
-            for (int r = 0; r < 12; ++r) {                          // piece wv + 4r
-                const int g = (wv + 4 * r) * 64 + ln;
-                const int row = g >> 3, cp = (g & 7) ^ (row & 7);
-                int hy = row / S, hx = row - hy * S;
-                if (hx > TC + 1) hx = TC + 1;                       // pad columns: any valid address
-                if (hy > TR + 1) hy = TR + 1;                       // pieces >= 45 are never issued
-                hoff[r] = ((uint32_t)hy * (uint32_t)a.in_sh + (uint32_t)hx * (uint32_t)cin) * 2u + cp * 16;
-            }
-        }
-        if (first) {
-            stage_halo(cur.xb, 0);
-            stage_weights(cur.wb, 0, 0, 0);
-            first = false;
-            if (STAMP) {
-                stamp(1);
+        };
+
+        if (DSFUSE) {
+            // ---- pre-phase: acc = Wd * x (1x1: the centre tap of x's halo), ds_cin / 64 steps ----
+            const int dcin = a.ds_cin, nds = dcin / kBK;
+            const int tw0 = cur.mt % a.tilesW, t20 = cur.mt / a.tilesW;
+            const int th0 = t20 % a.tilesH, img0 = t20 / a.tilesH;
+            const char* dxb = (const char*)(a.ds_x + img0 * a.ds_in_sb + (int64_t)(th0 * TR) * a.ds_in_sh +
+                                            (int64_t)(tw0 * TC) * dcin);
+            const char* dwb = (const char*)(a.ds_w + (int64_t)cur.n0 * dcin);
+            uint32_t woff_x[4];
+            lane_offsets(dcin, a.ds_in_sh, woff_x, true);
+            lane_offsets(cin, a.in_sh, woff, false);
+            stage_halo(dxb, 0);
+            stage_w(dwb, dcin, woff_x, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll 1
+            for (int kc = 0; kc < nds; ++kc) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                stamp(2);
+                asm volatile("" ::: "memory");
+                const char *be, *bo;
+                b_ptrs(4, be, bo);
+                mma_step(smem + (kc & 1) * 16384, be, bo, [&] {
+                    if (kc + 1 < nds) stage_w(dwb, dcin, woff_x, kc + 1, 0, (kc + 1) & 1);
+                    else stage_w(cur.wb, cin, woff, 0, 0, (kc + 1) & 1);            // conv2's first step
+                });
+                __builtin_amdgcn_s_barrier();                 // every wave has consumed this chunk's fragments
+                asm volatile("" ::: "memory");
+                if (kc + 1 < nds) {
+                    stage_halo(dxb, kc + 1);
+                } else {
+                    lane_offsets(cin, a.in_sh, woff, true);   // from here on the halo holds conv2's input t
+                    stage_halo(cur.xb, 0);
+                }
             }
-        }
-
-        // accumulators start at the folded-BN bias (its load hides behind the first operands' DMA)
-        f32x4 acc[JT][4];
+            kbase = nds;
+            // residual term and conv2's bias: acc <- (Wd*x + bd) / s + b2   (the epilogue multiplies by s)
+            const float* sc = a.se_scale + (int64_t)img0 * a.Cout + cur.n0 + q * 8;
 #pragma unroll
-        for (int j = 0; j < JT; ++j) {
-            const f32x4 b4 = *(const f32x4*)(a.bias + cur.n0 + q * 8 + acc_cout_offset(j));
+            for (int j = 0; j < JT; ++j) {
+                const int o = acc_cout_offset(j);
+                const f32x4 bd = *(const f32x4*)(a.ds_bias + cur.n0 + q * 8 + o);
+                const f32x4 b2 = *(const f32x4*)(a.bias + cur.n0 + q * 8 + o);
+                const f32x4 s4 = *(const f32x4*)(sc + o);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[j][n] = b4;
+                for (int i = 0; i < 4; ++i) {
+                    const float inv = __builtin_amdgcn_rcpf(fmaxf(s4[i], kSeScaleFloor));
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[j][n][i] = fmaf(acc[j][n][i] + bd[i], inv, b2[i]);
+                }
+            }
+        } else {
+            if (PERSIST || first) lane_offsets(cin, a.in_sh, woff, true);
+            if (first) {
+                stage_halo(cur.xb, 0);
+                stage_weights(cur.wb, 0, 0, 0);
+                first = false;
+                if (STAMP) {
+                    stamp(1);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    stamp(2);
+                }
+            }
+            // accumulators start at the folded-BN bias (its load hides behind the first operands' DMA)
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const f32x4 b4 = *(const f32x4*)(a.bias + cur.n0 + q * 8 + acc_cout_offset(j));
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[j][n] = b4;
+            }
         }
 
         // Retire every scalar (kernarg) load before the loop. A load still pending at the loop header keeps
@@ -926,32 +1060,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                const int tdy = tap / 3, dx = tap - tdy * 3 - 1;
-                const int u = wcol + c + 1 + dx;
-                const int v0 = u * 128 + (((q ^ (u & 7) ^ ((tdy & 1) << 2)) & 7) << 4);
-                const char* hb = smem + hbuf + tdy * (S * 128);
-                const char* be = hb + v0;
-                const char* bo = hb + (v0 ^ 64);
-                const char* wt = smem + ((kbase + k) & 1) * 16384;
-                f16x8 ar[3][2], bq[2][4];
-                auto read_a = [&](int g, f16x8 (&dst)[2]) {
-                    const int ks = g >> 2, jp = g & 3;
-                    const char* base = wt + (ks ? aoff1 : aoff0);
-                    dst[0] = *(const f16x8*)(base + (2 * jp) * 2048);
-                    dst[1] = *(const f16x8*)(base + (2 * jp + 1) * 2048);
-                };
-                auto read_b = [&](int ks, f16x8 (&dst)[4]) {
-#pragma unroll
-                    for (int n = 0; n < 4; ++n)
-                        dst[n] = *(const f16x8*)((((n & 1) ^ ks) ? bo : be) + n * (S * 128));
-                };
-                __builtin_amdgcn_sched_barrier(0);
-                read_b(0, bq[0]);
-                read_a(0, ar[0]);
-                __builtin_amdgcn_sched_barrier(0);
-                read_a(1, ar[1]);
-                __builtin_amdgcn_sched_barrier(0);
-                {   // the next K step's weights into the other buffer; on a tile's last step that is the
+                const char *be, *bo;
+                b_ptrs(tap, be, bo);
+                mma_step(smem + ((kbase + k) & 1) * 16384, be, bo, [&] {
+                    // the next K step's weights into the other buffer; on a tile's last step that is the
                     // next tile's first step (persistent variant only)
                     const bool more = k + 1 < nk;
                     const bool wrap = tap == 8;
@@ -961,24 +1073,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                     // nothing to stage on the very last step: no DMA is then in flight when the epilogue
                     // starts, so the workgroup can retire without waiting for its output stores
                     if (more || has_next) stage_weights(wsrc, kc1, tap1, (kbase + k + 1) & 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const int ks = g >> 2, jp = g & 3;
-                    if (g + 2 < 8) read_a(g + 2, ar[(g + 2) % 3]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (g == 1) { read_b(1, bq[1]); __builtin_amdgcn_sched_barrier(0); }
-                    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                        for (int n = 0; n < 4; ++n)
-                            acc[2 * jp + jj][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                                ar[g % 3][jj], bq[ks][n], acc[2 * jp + jj][n], 0, 0, 0);
-                    __builtin_amdgcn_s_setprio(0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                });
             }
             if ((next_chunk || has_next) && !(a.dbg & 32)) {     // dbg 32: timing experiment without the reload
                 // single halo buffer: every wave has consumed its last B fragments of this chunk (they fed
@@ -1005,7 +1100,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             const int t2 = cur.mt / a.tilesW;
             const int th = t2 % a.tilesH;
             const int img = t2 / a.tilesH;
-            conv_epilogue<WN, WM, JT, false, SPLIT, true, true>(a, acc, smem + kHalo4Lds, tid, lane, 0, wm, cur.n0, cur.mt,
+            conv_epilogue<WN, WM, JT, false, SPLIT, true, true, DSFUSE>(a, acc, smem + kHalo4Lds, tid, lane, 0, wm, cur.n0, cur.mt,
                                                           img, th, tw, th * TR + wrow, tw * TC + wcol,
                                                           STAMP ? a.stamps + (size_t)blockIdx.x * 16 : nullptr);
         }
@@ -1055,6 +1150,18 @@ static hipError_t launch_conv_halo4_tp(const ConvArgs& a0, hipStream_t s) {
 }
 template <int GEOM, bool SPLIT>
 static hipError_t launch_conv_halo4_t(const ConvArgs& a, hipStream_t s) {
+    if (a.ds_x != nullptr) {
+        if (GEOM != 0 || SPLIT) return hipErrorInvalidValue;      // (engine only fuses on the default f16 16x16 path)
+        static bool done_ds[64] = {};
+        hipError_t e0 = raise_lds_limit((const void*)conv3x3_halo4_kernel<0, false, false, false, true>, kHalo4LdsTotal, done_ds);
+        if (e0 != hipSuccess) return e0;
+        static const int dbg = [] { const char* e = getenv("HCTR_DBG"); return e ? atoi(e) : 0; }();
+        ConvArgs b = a;
+        b.dbg = dbg;
+        hipLaunchKernelGGL((conv3x3_halo4_kernel<0, false, false, false, true>), dim3(a.mtiles * a.ntiles), dim3(256),
+                           kHalo4LdsTotal, s, b);
+        return hipGetLastError();
+    }
     if (a.stamps != nullptr && !SPLIT) {
         static bool done[64] = {};
         hipError_t e0 = raise_lds_limit((const void*)conv3x3_halo4_kernel<GEOM, false, false, true>, kHalo4LdsTotal, done);
