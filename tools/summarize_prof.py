@@ -21,7 +21,7 @@ def short(name):
                   "log_softmax_rows_kernel", "row_candidates_kernel"):
             if k in name:
                 return k
-    return name.split("(")[0][:44]
+    return name.split("(")[0][:64]
 
 
 def main(d):
