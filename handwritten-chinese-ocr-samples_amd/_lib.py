@@ -131,7 +131,12 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if _stale():
+    # HCTR_LIB_PATH: load an alternative build of the library as it is (same-box A/B of compile-time switches)
+    alt = os.environ.get("HCTR_LIB_PATH", "")
+    if alt:
+        if not os.path.isfile(alt):
+            raise RuntimeError("HCTR_LIB_PATH=%s does not exist" % alt)
+    elif _stale():
         try:
             build()
         except (OSError, subprocess.CalledProcessError) as exc:
@@ -146,7 +151,7 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(alt or LIB_PATH)
     for name, res, args in SIGNATURES:
         fn = getattr(lib, name)          # AttributeError if the ABI drifted from the header
         fn.restype = res

@@ -6,6 +6,16 @@
 
 #include <cstdlib>
 
+#ifndef RING
+#define RING 3         // A-fragment ring slots (prefetch distance RING-1 groups)
+#endif
+#ifndef BHALF_AT
+#define BHALF_AT 1     // MFMA group before which the second half of the B fragments is read
+#endif
+#ifndef NOPRIO
+#define NOPRIO 0       // A/B build switch (tools/ab_build.sh): 1 drops the s_setprio around MFMA groups
+#endif
+
 namespace hctr {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -934,7 +944,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         // groups ahead into a 3-slot ring, the second half's B fragments during group 1; `stage_next` issues the
         // next step's weight DMA after the first reads so its issue cost overlaps their LDS latency.
         auto mma_step = [&](const char* wt, const char* be, const char* bo, auto&& stage_next) {
-            f16x8 ar[3][2], bq[2][4];
+            f16x8 ar[RING][2], bq[2][4];
             auto read_a = [&](int g, f16x8 (&dst)[2]) {
                 const int ks = g >> 2, jp = g & 3;
                 const char* base = wt + (ks ? aoff1 : aoff0);
@@ -951,23 +961,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             read_a(0, ar[0]);
             __builtin_amdgcn_sched_barrier(0);
             read_a(1, ar[1]);
+            if (RING > 3) read_a(2, ar[2]);
             __builtin_amdgcn_sched_barrier(0);
             stage_next();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const int ks = g >> 2, jp = g & 3;
-                if (g + 2 < 8) read_a(g + 2, ar[(g + 2) % 3]);
+                if (g + RING - 1 < 8) read_a(g + RING - 1, ar[(g + RING - 1) % RING]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (g == 1) { read_b(1, bq[1]); __builtin_amdgcn_sched_barrier(0); }
-                __builtin_amdgcn_s_setprio(1);
+                if (g == BHALF_AT) { read_b(1, bq[1]); __builtin_amdgcn_sched_barrier(0); }
+                if (!(NOPRIO)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
                         acc[2 * jp + jj][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                            ar[g % 3][jj], bq[ks][n], acc[2 * jp + jj][n], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
+                            ar[g % RING][jj], bq[ks][n], acc[2 * jp + jj][n], 0, 0, 0);
+                if (!(NOPRIO)) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
