@@ -1132,7 +1132,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     }
 }
 
-constexpr int kHalo4LdsTotal = kHalo4Lds + 4 * 128 * 4;   // + [WM][BN] floats of epilogue scratch
+#ifndef LDS_PAD
+#define LDS_PAD 0      // A/B build switch: extra LDS bytes per workgroup (e.g. 40000 forces ONE workgroup per CU)
+#endif
+constexpr int kHalo4LdsTotal = kHalo4Lds + 4 * 128 * 4 + LDS_PAD;   // + [WM][BN] floats of epilogue scratch
 
 template <int GEOM, bool SPLIT, bool PERSIST>
 static hipError_t launch_conv_halo4_tp(const ConvArgs& a0, hipStream_t s) {
