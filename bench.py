@@ -172,7 +172,7 @@ def main():
                           "tflops": round(FLOP_PER_COL_ALL * cols / (kernel_ms * 1e-3) / 1e12, 2)},
     }
 
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 of the 1-GPU run only
         from oracle import ctc_ref, hctr_ref
         nl = max(1, args.cpu_lines)
         x = synth.normalize_pad(imgs_host[:nl])
