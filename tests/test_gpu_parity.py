@@ -69,8 +69,11 @@ def test_forward_matches_reference_fixture(engine, synth, name, seed, widths):
     assert np.array_equal(got.argmax(axis=2)[safe], ref_arg[safe])
     assert (got.argmax(axis=2) == ref_arg).mean() >= MIN_AGREE
     # activations along the trunk (debug taps) against the reference's
-    for tap in ("stage0", "stage2", "stage4"):
-        a = engine.debug_activation(tap, len(widths))[:, :8, :, :16]
+    # block1.0 = first block of stage 1: fused SE + the 1x1 downsample branch inside conv2's K loop (buffer p1.1);
+    # block3.4 = last block of stage 3 (buffer p3.0)   [buffer rotation: engine.cpp run_forward]
+    for tap, buf in (("stage0", "stage0"), ("stage2", "stage2"), ("stage4", "stage4"), ("block1.0", "p1.1"),
+                     ("block3.4", "p3.0")):
+        a = engine.debug_activation(buf, len(widths))[:, :8, :, :16]
         r = g[name + "/act/" + tap]
         assert np.abs(a - r).max() <= 0.02 * np.abs(r).max() + 0.02, tap
 
@@ -627,3 +630,33 @@ def test_stamped_diagnostic_instance_keeps_results(engine, pkg, synth):
     assert n == 2 * 1 * 6 * 4                                      # images x tile rows x tile columns x cout tiles
     t = out[:n, :6].astype(np.int64)
     assert (np.diff(t, axis=1) >= 0).all() and (t[:, 5] - t[:, 0]).max() < 10 ** 7
+
+
+@pytest.mark.parametrize("name,seed,widths", [("b2w300u", 51, [300, 211]), ("b4w131u", 52, [131, 100, 64, 17])])
+def test_forward_matches_reference_extra_fixtures(engine, codec, synth, name, seed, widths):
+    """Engine vs the REAL reference on strongly unequal widths (tests/golden/model_extra.npz): logits, argmax on
+    safe columns, trunk activations incl. the fused-downsample block, greedy text within the ambiguous-column bound."""
+    g = np.load(os.path.join(GOLDEN, "model_extra.npz"))
+    with open(os.path.join(GOLDEN, "model_extra_strings.json"), encoding="utf-8") as f:
+        strings = json.load(f)[name]
+    imgs = synth.make_line_images(len(widths), max(widths), seed)
+    got = engine(imgs, widths=widths)
+    ref_sub = g[name + "/logits_sub"]
+    tol = LOGIT_RTOL * float(np.abs(ref_sub).max()) + LOGIT_ATOL
+    err = float(np.abs(got[:, :, g["sub_classes"]] - ref_sub).max())
+    assert err <= tol, "max logit error %.4f > %.4f" % (err, tol)
+    margin = g[name + "/top10_val"][:, :, 0] - g[name + "/top10_val"][:, :, 1]
+    safe = margin > 2 * err
+    ref_arg = g[name + "/argmax"].astype(np.int64)
+    assert np.array_equal(got.argmax(axis=2)[safe], ref_arg[safe])
+    assert (got.argmax(axis=2) == ref_arg).mean() >= MIN_AGREE
+    for tap, buf in (("stage1", "stage1"), ("stage3", "stage3"), ("block1.0", "p1.1"), ("block3.4", "p3.0")):
+        a = engine.debug_activation(buf, len(widths))[:, :8, :, :16]
+        r = g[name + "/act/" + tap]
+        assert np.abs(a - r).max() <= 0.02 * np.abs(r).max() + 0.02, tap
+    text = codec.labels_to_text(engine.greedy(imgs, widths=widths))
+    for b, (mine, want) in enumerate(zip(text, strings["greedy"])):
+        amb = int((~safe[:, b]).sum())
+        assert ctc_ref.edit_distance(mine, want) <= 2 * amb, (b, amb)
+        if amb == 0:
+            assert mine == want

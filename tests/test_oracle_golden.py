@@ -104,3 +104,34 @@ def test_edit_distance():
     assert ctc_ref.edit_distance("kitten", "sitting") == 3
     assert ctc_ref.edit_distance("", "abc") == 3
     assert ctc_ref.edit_distance("abc", "abc") == 0
+
+
+@pytest.mark.parametrize("name,seed,widths", [("b2w300u", 51, [300, 211]), ("b4w131u", 52, [131, 100, 64, 17])])
+def test_oracle_matches_reference_extra_fixtures(synth, state_dict, name, seed, widths):
+    """tests/golden/model_extra.npz (make_golden_extra.py: the REAL reference on strongly unequal widths, where
+    the replicate pad dominates some lines' SE means), incl. its beam-search strings on the same logits."""
+    g = np.load(os.path.join(GOLDEN, "model_extra.npz"))
+    with open(os.path.join(GOLDEN, "model_extra_strings.json"), encoding="utf-8") as f:
+        strings = json.load(f)[name]
+    imgs = synth.make_line_images(len(widths), max(widths), seed)
+    taps = {}
+    logits = hctr_ref.forward(state_dict, synth.normalize_pad(imgs, widths), taps).numpy()
+    sub = g["sub_classes"]
+    np.testing.assert_allclose(logits[:, :, sub], g[name + "/logits_sub"], atol=LOGIT_ATOL, rtol=0)
+    np.testing.assert_allclose(logits.max(axis=2), g[name + "/max"], atol=LOGIT_ATOL, rtol=0)
+    for k in ("stage1", "stage3", "block1.0", "block3.4"):
+        np.testing.assert_allclose(taps[k][:, :8, :, :16].numpy(), g[name + "/act/" + k], atol=1e-4, rtol=0)
+    margin = g[name + "/top10_val"][:, :, 0] - g[name + "/top10_val"][:, :, 1]
+    safe = margin > 4 * LOGIT_ATOL
+    assert np.array_equal(logits.argmax(axis=2)[safe], g[name + "/argmax"][safe].astype(np.int64))
+    codec = ctc_ref.CtcCodecRef(synth.characters())
+    if safe.all():
+        assert codec.decode(logits) == strings["greedy"]
+        for tag, skip, lm, lp, lb, bs, depth in codec_cases.BEAM_SETTINGS[:4]:
+            if tag not in strings:
+                continue
+            oc = ctc_ref.CtcCodecRef(synth.characters())
+            oc.use_beam_search, oc.skip_search, oc.use_tfm_pred = True, skip, False
+            oc.lm_panelty, oc.len_bonus, oc.beam_size, oc.search_depth = lp, lb, bs, depth
+            oc.ngram = ctc_ref.ZeroLM() if lm == "zero" else ctc_ref.ToyBigramLM()
+            assert oc.decode(logits) == strings[tag], tag
