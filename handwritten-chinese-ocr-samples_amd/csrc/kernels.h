@@ -51,8 +51,11 @@ struct ConvArgs {
     int ds_cin;
     int ds_in_sh;             // elements per image row of ds_x
     int64_t ds_in_sb;         // elements per image of ds_x
-    unsigned long long* stamps;   // diagnostic build only (hctr_debug_stamps): 8 x u64 per workgroup, else NULL
-    int dbg;                // timing experiments only (HCTR_DBG): 1 = DMA from fixed hot addresses, 2 = no DMA in the loop
+    unsigned long long* stamps;   // diagnostic instance only (hctr_debug_stamps): 16 x u64 per workgroup, else NULL
+    // timing experiments only (HCTR_DBG), results INVALID. 8-wave/generic kernels: 1 = DMA from fixed hot addresses,
+    // 2 = no DMA in the loop. halo4 kernel, bit mask: 32 = no halo reload at chunk boundaries, 64 = no K loop,
+    // 128 = no epilogue, 256 = no output stores.
+    int dbg;
 };
 
 // tile configurations: (couts x pixels) per 256-thread block
