@@ -152,7 +152,12 @@ def load():
     except ImportError:
         pass
     lib = ctypes.CDLL(alt or LIB_PATH)
+    # HCTR_HOST_ONLY=1 (with HCTR_LIB_PATH): a sanitizer build of the pure-host sources only (beam search, n-gram
+    # scorer; tools/build_host_sanitized.sh) - the device entry points are then absent and stay unbound
+    host_only = bool(alt) and os.environ.get("HCTR_HOST_ONLY", "") == "1"
     for name, res, args in SIGNATURES:
+        if host_only and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)          # AttributeError if the ABI drifted from the header
         fn.restype = res
         fn.argtypes = args

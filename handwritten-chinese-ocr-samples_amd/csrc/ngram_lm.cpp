@@ -62,7 +62,7 @@ double ngram_word_logp(const hctr_ngram* lm, const int32_t* ctx, int nctx, int32
     double backoff = 0.0;
     int32_t buf[16];
     for (int n = use; n >= 0; --n) {                   // n context words + the word itself
-        memcpy(buf, c + (use - n), (size_t)n * 4);
+        if (n > 0) memcpy(buf, c + (use - n), (size_t)n * 4);      // (ctx may be NULL when nctx == 0)
         buf[n] = word;
         const auto& tab = lm->tables[n];
         auto it = tab.find(key_of(buf, n + 1));
