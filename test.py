@@ -13,6 +13,8 @@ Differences from the reference, by design:
     HBM - pixel parity with cv2 is unpinned (DESIGN.md section 2);
   * ``-bm`` applies AlignCollate's width cap of 1600 columns with its proportional label cut
     (utils/dataset.py:111-148, built with the default max_width at test.py:235);
+  * ``-jw N`` decodes the next batches' image files on N host threads while the GPU works on the current one
+    (the reference's DataLoader workers, test.py:240-245); ``-jw 0`` decodes inline;
   * ``-f synthetic[:seed]`` loads the package's deterministic synthetic checkpoint (no checkpoint files
     are bundled with the reference), and then the vocabulary defaults to the synthetic one;
   * ``-kp zero|toy`` selects a built-in language model for beam search when kenlm is not installed.
@@ -88,12 +90,28 @@ def list_inputs(path):
     return hctr_amd.preprocess.list_inputs(path)
 
 
-def load_batch(model, paths, rule, max_width=None):
-    """Decode on the host, then gray + INTER_AREA resize + packing on the device; the batch stays in HBM."""
+def prefetched(batches, workers):
+    """Yield (batch, decoded images) with the NEXT batches' files already being decoded on ``workers`` host threads
+    (the reference's DataLoader(num_workers=args.workers), test.py:240-245; PIL releases the GIL while decoding),
+    so that JPEG/PNG decode overlaps the GPU work of the current batch."""
     import hctr_amd
-    pp = hctr_amd.preprocess
-    return pp.resize_lines(model, [pp.load_image(p) for p in paths], model.img_height, rule, "rgb", max_width,
-                           device_out=True)
+    from concurrent.futures import ThreadPoolExecutor
+    load = hctr_amd.preprocess.load_image
+    if workers <= 0:
+        for b in batches:
+            yield b, [load(p) for p in b]
+        return
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        depth = 2                                            # batches in flight beyond the current one
+        queue = []
+        it = iter(batches)
+        for b in it:
+            queue.append((b, [pool.submit(load, p) for p in b]))
+            if len(queue) > depth:
+                bb, futs = queue.pop(0)
+                yield bb, [f.result() for f in futs]
+        for bb, futs in queue:
+            yield bb, [f.result() for f in futs]
 
 
 def edit_distance(a, b):
@@ -155,10 +173,13 @@ def test(args):
     model, codec = build(args)
     if args.benchmark_mode:
         return benchmark(model, codec, args)
+    import hctr_amd
+    pp = hctr_amd.preprocess
     paths = list_inputs(args.input)
-    for i in range(len(paths) // args.batch_size):
+    batches = [paths[i * args.batch_size:(i + 1) * args.batch_size] for i in range(len(paths) // args.batch_size)]
+    for i, (_, arrs) in enumerate(prefetched(batches, args.workers)):
         print("batch {} is being processed...".format(i))
-        imgs, widths = load_batch(model, paths[i * args.batch_size:(i + 1) * args.batch_size], "test")
+        imgs, widths = pp.resize_lines(model, arrs, model.img_height, "test", "rgb", None, device_out=True)
         t0 = time.time()
         result = recognise(model, codec, imgs, widths)
         dt = time.time() - t0
@@ -190,9 +211,10 @@ def benchmark(model, codec, args):
     total = nchars = 0
     cer = 0.0
     t_all = time.time()
-    for i in range(0, len(items), args.batch_size):
-        chunk = items[i:i + args.batch_size]
-        arrs = [pp.load_image(n) for n, _ in chunk]
+    chunks = [items[i:i + args.batch_size] for i in range(0, len(items), args.batch_size)]
+    for bi, (names, arrs) in enumerate(prefetched([[n for n, _ in ch] for ch in chunks], args.workers)):
+        i = bi * args.batch_size
+        chunk = chunks[bi]
         full = [pp.target_width(a.shape[0], a.shape[1], model.img_height, "dataset") for a in arrs]
         imgs, widths = pp.resize_lines(model, arrs, model.img_height, "dataset", "rgb", ALIGN_MAX_WIDTH, device_out=True)
         chunk = [(n, pp.truncate_label(tru, fw, int(imgs.shape[2]))) for (n, tru), fw in zip(chunk, full)]
