@@ -660,3 +660,33 @@ def test_forward_matches_reference_extra_fixtures(engine, codec, synth, name, se
         assert ctc_ref.edit_distance(mine, want) <= 2 * amb, (b, amb)
         if amb == 0:
             assert mine == want
+
+
+def test_plain_c_caller_matches_python(tmp_path, engine, synth):
+    """examples/greedy_demo.c - C99, no Python, no torch - drives the C ABI directly (weights from
+    tools/export_weights.py) and must print the labels the Python shim returns."""
+    import shutil
+    import subprocess
+    import sys
+    from conftest import ROOT
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    libdir = os.path.join(ROOT, "handwritten-chinese-ocr-samples_amd")
+    exe = str(tmp_path / "greedy_demo")
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "greedy_demo.c"),
+                        "-L", libdir, "-lhctr_hip", "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    wfile = str(tmp_path / "weights.bin")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "export_weights.py"), "synthetic", wfile],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    W = 333
+    img = synth.make_line_images(1, W, 91)
+    img[0].tofile(str(tmp_path / "line.u8"))
+    r = subprocess.run([exe, wfile, str(synth.DEFAULT_VOCAB + 2), str(tmp_path / "line.u8"), str(W)], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    want = engine.greedy(img)[0]
+    line = [ln for ln in r.stdout.splitlines() if "labels:" in ln][0]
+    got = [int(t) for t in line.split("labels:")[1].split()]
+    assert got == want.tolist() and int(line.split()[0]) == len(want)
