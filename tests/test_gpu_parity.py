@@ -690,3 +690,32 @@ def test_plain_c_caller_matches_python(tmp_path, engine, synth):
     line = [ln for ln in r.stdout.splitlines() if "labels:" in ln][0]
     got = [int(t) for t in line.split("labels:")[1].split()]
     assert got == want.tolist() and int(line.split()[0]) == len(want)
+
+
+def test_two_contexts_on_two_threads(pkg, engine, synth, state_dict):
+    """Threading contract of the C ABI: a context is not re-entrant, but independent contexts may
+    run concurrently from different host threads (ctypes releases the GIL) - results equal the serial ones."""
+    import threading
+    other = pkg.hctr_model(synth.DEFAULT_VOCAB + 2).cuda(0)
+    other.load_state_dict(state_dict)
+    jobs = [(engine, synth.make_line_images(3, 300, 71)), (other, synth.make_line_images(2, 411, 72))]
+    serial = [m.greedy(x) for m, x in jobs]
+    out = [None, None]
+    errs = []
+
+    def work(i):
+        try:
+            m, x = jobs[i]
+            for _ in range(4):
+                out[i] = m.greedy(x)
+        except BaseException as exc:                          # noqa: BLE001
+            errs.append(exc)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for got, want in zip(out, serial):
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
