@@ -156,6 +156,8 @@ class hctr_model(object):
                 if x.dim() != 3 or x.shape[1] != 128:
                     raise ValueError("uint8 input must be [B,128,W]")
                 x = x.contiguous()
+                if x.is_cuda:        # the engine runs on its own stream: torch work that produced x must be done
+                    torch.cuda.current_stream(x.device).synchronize()
                 return x, _lib.U8, int(x.is_cuda), x.shape[0], x.shape[2]
             if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != 128:
                 raise ValueError("input must be float [B,1,128,W], got %s" % (tuple(x.shape),))
