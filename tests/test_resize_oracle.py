@@ -85,3 +85,16 @@ def test_host_width_rules_match_oracle(pkg):
     assert pp.truncate_label("abcdefghij", 2000, 1600) == R.truncate_label("abcdefghij", 2000, 1600)
     with pytest.raises(ValueError):
         pp.target_width(1, 1, 128, "other")
+
+
+def test_integer_decimation_agrees_with_an_independent_box_filter():
+    """Not a cv2 pin (PIL is a different library with its own rounding), but an independent implementation of the
+    same box average: for integer factors PIL's BOX resampling and the oracle differ by at most one grey level."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    for h, w in ((256, 600), (384, 900), (512, 64)):
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        tw = R.target_width(h, w)
+        o = R.resize_area(a, tw, 128).astype(int)
+        p = np.asarray(Image.fromarray(a).resize((tw, 128), Image.BOX)).astype(int)
+        assert o.shape == p.shape and np.abs(o - p).max() <= 1
