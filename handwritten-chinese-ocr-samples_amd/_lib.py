@@ -25,13 +25,44 @@ ERR_ARG, ERR_HIP, ERR_STATE, ERR_KEY, ERR_SHAPE, ERR_EMPTY_LINE, ERR_NOMEM = -1,
 U8, F32, I64 = 0, 1, 2
 
 
-def _stale():
-    if not os.path.isfile(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, "kernels.h"),
+def _deps():
+    return [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, "kernels.h"),
                                                           os.path.join(CSRC, "ngram_lm.h"), HEADER]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
+
+
+def source_hash():
+    """16 hex digits over the contents of every source the library is built from and the compile flags.
+    Compiled into the library (``hctr_version()`` ends in ``src=<hash>``), so "is this binary built from these
+    sources" does not depend on file times (a snapshot copied to the GPU box keeps no useful mtimes)."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(repr((COMMON, SOURCES)).encode())
+    for d in sorted(_deps()):
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+_MARK = b"hctr-src="
+
+
+def embedded_hash(path=None):
+    """The source hash compiled into a built library, read from the file (None if absent)."""
+    path = path or LIB_PATH
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    i = blob.find(_MARK)
+    if i < 0:
+        return None
+    return blob[i + len(_MARK):i + len(_MARK) + 16].decode("ascii", "replace")
+
+
+def _stale():
+    return embedded_hash() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -59,19 +90,35 @@ def _build_locked(verbose):
     objdir = os.path.join(PKG_DIR, "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []
+    srch = source_hash()
     for src, extra in SOURCES:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        if src == "engine.cpp":
+            extra = extra + ['-DHCTR_SRC_HASH="%s"' % srch]
         cmd = [hipcc] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        # an object is reused when its source, the headers and its command line are unchanged
+        import hashlib
+        h = hashlib.sha256(repr(cmd).encode())
+        for d in [os.path.join(CSRC, src), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "ngram_lm.h"), HEADER]:
+            with open(d, "rb") as f:
+                h.update(f.read())
+        tag, tagfile = h.hexdigest(), obj + ".tag"
+        if os.path.isfile(obj) and os.path.isfile(tagfile) and open(tagfile).read() == tag:
+            continue
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
+        with open(tagfile, "w") as f:
+            f.write(tag)
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
     os.replace(tmp, LIB_PATH)
+    if embedded_hash() != srch:
+        raise OSError("built library does not carry the source hash %s" % srch)
     return LIB_PATH
 
 
@@ -137,12 +184,20 @@ def load():
         if not os.path.isfile(alt):
             raise RuntimeError("HCTR_LIB_PATH=%s does not exist" % alt)
     elif _stale():
+        # A failed rebuild is an error: silently loading the previous binary would run tests and benches against
+        # code that no longer matches the sources. The one exception is a machine without hipcc (FileNotFoundError)
+        # that was shipped a prebuilt library - then that library is used, with a warning.
         try:
             build()
-        except (OSError, subprocess.CalledProcessError) as exc:
+        except FileNotFoundError as exc:
             if not os.path.isfile(LIB_PATH):
-                raise RuntimeError("libhctr_hip.so is missing and could not be built with hipcc (%s); "
+                raise RuntimeError("libhctr_hip.so is missing and hipcc is not available (%s); "
                                    "the hctr engine has no CPU fallback" % exc)
+            print("hctr: WARNING: sources are newer than libhctr_hip.so but hipcc is not available; "
+                  "loading the prebuilt library", file=sys.stderr)
+        except (OSError, subprocess.CalledProcessError) as exc:
+            raise RuntimeError("libhctr_hip.so is out of date and rebuilding it failed (%s); fix the build "
+                               "(python -c 'import hctr_amd; hctr_amd.build(force=True, verbose=True)')" % exc)
     # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7 (same SONAME as /opt/rocm's).
     # Loaded first, it is the copy this library binds to as well, so device pointers of torch tensors
     # (on_device arguments, DLPack-free interop) and the engine's own allocations share a runtime; loaded
@@ -152,6 +207,9 @@ def load():
     except ImportError:
         pass
     lib = ctypes.CDLL(alt or LIB_PATH)
+    if not alt and embedded_hash() != source_hash():
+        print("hctr: WARNING: libhctr_hip.so was built from other sources than csrc/ holds now (%s vs %s)"
+              % (embedded_hash(), source_hash()), file=sys.stderr)
     # HCTR_HOST_ONLY=1 (with HCTR_LIB_PATH): a sanitizer build of the pure-host sources only (beam search, n-gram
     # scorer; tools/build_host_sanitized.sh) - the device entry points are then absent and stay unbound
     host_only = bool(alt) and os.environ.get("HCTR_HOST_ONLY", "") == "1"

@@ -282,9 +282,15 @@ class ctc_codec(object):
                 try:
                     prefixes = ["".join(chars[ids[j]] for j in range(offs[i], offs[i + 1])) for i in range(n)]
                     words = tfm.next_k_words(prefixes, k=depth, char_based=True)
+                    # the reference chains whatever the LM returns (utils/ctc_codec.py:225-226): a shorter list is
+                    # padded with the <unknown> id, which the search skips like the reference does (:238-239)
+                    unk = len(chars) - 1
                     for i in range(n):
+                        wl = list(words[i])
+                        if len(wl) > kk:
+                            raise ValueError("next_k_words returned %d words for k=%d" % (len(wl), kk))
                         for j in range(kk):
-                            out_ids[i * kk + j] = cdict[words[i][j]]
+                            out_ids[i * kk + j] = cdict[wl[j]] if j < len(wl) else unk
                     return 0
                 except BaseException as exc:
                     err.append(exc)

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <new>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -343,22 +344,46 @@ extern "C" int hctr_beam_search(const hctr_beam_params* p, int W, int B, int C, 
     const bool callbacks = p->builtin_lm == 0 || p->next_cb != nullptr;
     int nthreads = callbacks ? 1 : std::max(1, p->num_threads);
     nthreads = std::min(nthreads, B);
+    for (int b = 0; b < B; ++b) { line_status[b] = HCTR_OK; out_lengths[b] = 0; }
+    // No C++ exception leaves this function or a worker thread (include/hctr_hip.h): a line whose search runs out
+    // of host memory reports HCTR_ERR_NOMEM, stops the remaining work and becomes the return value.
     std::atomic<int> next(0);
-    auto worker = [&]() {
+    std::atomic<int> fault(HCTR_OK);
+    auto worker = [&]() noexcept {
         for (;;) {
             const int b = next.fetch_add(1);
             if (b >= B) break;
-            LineInput in{W, B, C, k, b, topk_idx, topk_logp, blank_logp, cand_off, cand_idx, cand_logp, full_logp_wbc};
-            line_status[b] = decode_line(*p, in, out_labels + (size_t)b * W, out_lengths + b);
+            int st;
+            try {
+                LineInput in{W, B, C, k, b, topk_idx, topk_logp, blank_logp, cand_off, cand_idx, cand_logp, full_logp_wbc};
+                st = decode_line(*p, in, out_labels + (size_t)b * W, out_lengths + b);
+            } catch (const std::bad_alloc&) {
+                st = HCTR_ERR_NOMEM;
+            } catch (...) {
+                st = HCTR_ERR_STATE;
+            }
+            line_status[b] = st;
+            if (st == HCTR_ERR_NOMEM || st == HCTR_ERR_STATE) {
+                fault.store(st);
+                next.store(B);
+            }
         }
     };
     if (nthreads == 1) {
         worker();
     } else {
+        // a thread that cannot be created (EAGAIN under a process / address-space limit) is not fatal: the threads
+        // that did start - or this one - work through the lines
         std::vector<std::thread> th;
-        for (int i = 0; i < nthreads; ++i) th.emplace_back(worker);
+        try {
+            th.reserve((size_t)nthreads);
+            for (int i = 0; i < nthreads; ++i) th.emplace_back(worker);
+        } catch (...) {
+        }
+        if (th.empty()) worker();
         for (auto& t : th) t.join();
     }
+    if (fault.load() != HCTR_OK) return fault.load();
     for (int b = 0; b < B; ++b)
         if (line_status[b] != HCTR_OK) return line_status[b];
     return HCTR_OK;

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -138,6 +139,30 @@ int fail(hctr_ctx* c, int code, const char* fmt, ...) {
     return code;
 }
 
+// The ABI promises that no C++ exception crosses it (include/hctr_hip.h): every extern "C" body runs inside
+// guard(), which maps std::bad_alloc to HCTR_ERR_NOMEM and anything else to HCTR_ERR_STATE. Setting the message
+// may itself allocate, so that is attempted under its own handler.
+int fail_nothrow(hctr_ctx* c, int code, const char* what) noexcept {
+    try {
+        return fail(c, code, "%s", what);
+    } catch (...) {
+        return code;
+    }
+}
+
+template <typename R = int, typename F>
+R guard(hctr_ctx* c, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return (R)fail_nothrow(c, HCTR_ERR_NOMEM, "out of host memory (std::bad_alloc)");
+    } catch (const std::exception& e) {
+        return (R)fail_nothrow(c, HCTR_ERR_STATE, e.what());
+    } catch (...) {
+        return (R)fail_nothrow(c, HCTR_ERR_STATE, "unknown C++ exception");
+    }
+}
+
 #define HIP_TRY(ctx, expr)                                                                        \
     do {                                                                                          \
         hipError_t _e = (expr);                                                                   \
@@ -170,6 +195,11 @@ void free_pool(std::vector<void*>& pool) {
     for (void* p : pool) (void)hipFree(p);
     pool.clear();
 }
+
+struct PoolGuard {          // frees a call's temporaries on every exit path, exceptions included
+    std::vector<void*>& pool;
+    ~PoolGuard() { free_pool(pool); }
+};
 
 // ---------------------------------------------------------------------------------------------
 // checkpoint ingest
@@ -363,41 +393,67 @@ int ensure_workspace(hctr_ctx* c, int B, int W) {
         c->ws_cache.pop_back();
     }
     c->ws = Workspace();
-    int rc = HCTR_OK;
-    auto A = [&](auto** out, size_t count, bool zero) {
-        if (rc == HCTR_OK) rc = dev_alloc(c, ws.allocs, out, count, zero, &ws.bytes);
-    };
-    A((char**)&ws.img, (size_t)cols * kImgH * 4, false);
-    A(&ws.widths, (size_t)B, false);
     const int m = c->chm();
-    A(&ws.s0, (size_t)act_elems(B, 128, Wa, 64 * m), true);
-    int cin = 64;
-    size_t se_max = 0;
-    for (int s = 1; s <= 4; ++s) {
-        const int H = kStageH[s], planes = kStagePlanes[s - 1];
-        A(&ws.x[s], (size_t)act_elems(B, H, Wa, cin * m), true);
-        const int nbuf = (s == 4) ? 2 : 3;
-        for (int i = 0; i < nbuf; ++i) A(&ws.p[s][i], (size_t)act_elems(B, H, Wa, planes * m), true);
-        se_max = std::max(se_max, (size_t)B * (H / 8) * tilesW * planes);
-        cin = planes;
+    auto alloc_all = [&]() {
+        int rc = HCTR_OK;
+        auto A = [&](auto** out, size_t count, bool zero) {
+            if (rc == HCTR_OK) rc = dev_alloc(c, ws.allocs, out, count, zero, &ws.bytes);
+        };
+        A((char**)&ws.img, (size_t)cols * kImgH * 4, false);
+        A(&ws.widths, (size_t)B, false);
+        A(&ws.s0, (size_t)act_elems(B, 128, Wa, 64 * m), true);
+        int cin = 64;
+        size_t se_max = 0;
+        for (int s = 1; s <= 4; ++s) {
+            const int H = kStageH[s], planes = kStagePlanes[s - 1];
+            A(&ws.x[s], (size_t)act_elems(B, H, Wa, cin * m), true);
+            const int nbuf = (s == 4) ? 2 : 3;
+            for (int i = 0; i < nbuf; ++i) A(&ws.p[s][i], (size_t)act_elems(B, H, Wa, planes * m), true);
+            se_max = std::max(se_max, (size_t)B * (H / 8) * tilesW * planes);
+            cin = planes;
+        }
+        A(&ws.headin, (size_t)cols * kFeat * m, false);
+        // ws.logits ([B*W][cpad] fp32, 3.8 GB at config 2) is NOT allocated here: only the API-parity and unfused
+        // paths need it (ensure_logits)
+        A(&ws.se_part, se_max, false);
+        A(&ws.se_scale, (size_t)B * 512, false);
+        A(&ws.se_border, (size_t)B * 4 * 8 * 512, false);
+        A(&ws.se_mean, (size_t)B * 512, false);
+        A(&ws.colidx, (size_t)cols, false);
+        A(&ws.amax_val, (size_t)cols * (c->cpad / 64), false);
+        A(&ws.amax_idx, (size_t)cols * (c->cpad / 64), false);
+        A(&ws.labels, (size_t)cols, false);
+        A(&ws.lengths, (size_t)B, false);
+        return rc;
+    };
+    int rc = alloc_all();
+    if (rc == HCTR_ERR_NOMEM && !c->ws_cache.empty()) {
+        // the budget estimate was too optimistic for what the device has free: drop every cached workspace, retry once
+        free_pool(ws.allocs);
+        ws = Workspace();
+        ws.B = B; ws.W = W; ws.Wa = Wa;
+        for (auto& w : c->ws_cache) free_pool(w.allocs);
+        c->ws_cache.clear();
+        rc = alloc_all();
     }
-    A(&ws.headin, (size_t)cols * kFeat * m, false);
-    A(&ws.logits, (size_t)cols * c->cpad, false);
-    A(&ws.se_part, se_max, false);
-    A(&ws.se_scale, (size_t)B * 512, false);
-    A(&ws.se_border, (size_t)B * 4 * 8 * 512, false);
-    A(&ws.se_mean, (size_t)B * 512, false);
-    A(&ws.colidx, (size_t)cols, false);
-    A(&ws.amax_val, (size_t)cols * (c->cpad / 64), false);
-    A(&ws.amax_idx, (size_t)cols * (c->cpad / 64), false);
-    A(&ws.labels, (size_t)cols, false);
-    A(&ws.lengths, (size_t)B, false);
     if (rc != HCTR_OK) {
         free_pool(ws.allocs);
         return rc;
     }
     c->ws_cache.insert(c->ws_cache.begin(), ws);
     c->ws = ws;
+    return HCTR_OK;
+}
+
+// [B*W][cpad] fp32 logits of the active workspace, allocated on first use (hctr_forward_logits, caller-visible
+// log-probabilities, the HCTR_FUSE_* = 0 A/B paths). The fused greedy and beam paths never touch them.
+int ensure_logits(hctr_ctx* c) {
+    if (c->ws.logits) return HCTR_OK;
+    if (c->ws_cache.empty() || c->ws_cache.front().B != c->ws.B || c->ws_cache.front().W != c->ws.W)
+        return fail(c, HCTR_ERR_STATE, "no active workspace");
+    Workspace& slot = c->ws_cache.front();          // the active workspace is the cache's first entry
+    TRY(dev_alloc(c, slot.allocs, &slot.logits, (size_t)slot.B * slot.W * c->cpad, false, &slot.bytes));
+    c->ws = slot;
     return HCTR_OK;
 }
 
@@ -562,6 +618,7 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
 // decode, fused_argmax - only the per-column argmax in ws.colidx (the 29 kB-per-column logits never exist).
 // ResNet.forward :115-153 and hctr_model.forward :171-176; np.argmax(preds, 2) utils/ctc_codec.py:75.
 int run_forward(hctr_ctx* c, int img_f32, bool have_widths, bool fused_argmax = false) {
+    if (!fused_argmax) TRY(ensure_logits(c));
     Workspace& ws = c->ws;
     Prof pf(c);
     pf.begin("stem.conv0_1");
@@ -664,47 +721,54 @@ int sub_batch(hctr_ctx* c, int B, int W) {
 // =============================================================================================
 extern "C" {
 
+#ifndef HCTR_SRC_HASH
+#define HCTR_SRC_HASH "unhashed-build000"
+#endif
+// ends in the hash of the sources this binary was built from (_lib.py source_hash: stale-binary detection)
 const char* hctr_version(void) {
-    return "hctr-hip 0.1 (gfx950, f16 storage / f16 MFMA / f32 accumulate; optional f16x3 split precision)";
+    return "hctr-hip 0.2 (gfx950, f16 storage / f16 MFMA / f32 accumulate; optional f16x3 split precision) "
+           "hctr-src=" HCTR_SRC_HASH;
 }
 
 int hctr_create(hctr_ctx** out, int device, int num_classes) {
-    if (!out) return fail(nullptr, HCTR_ERR_ARG, "out is NULL");
-    *out = nullptr;
-    if (num_classes < 3) return fail(nullptr, HCTR_ERR_ARG, "num_classes must be >= 3 (blank + chars + unknown)");
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev == 0)
-        return fail(nullptr, HCTR_ERR_HIP, "no HIP device available (%s): the hctr engine has no CPU fallback",
-                    hipGetErrorString(e));
-    if (device < 0 || device >= ndev) return fail(nullptr, HCTR_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
-    e = hipSetDevice(device);
-    if (e != hipSuccess) return fail(nullptr, HCTR_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
-    hctr_ctx* c = new hctr_ctx();
-    c->device = device;
-    c->num_classes = num_classes;
-    c->cpad = (num_classes + 255) / 256 * 256;
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-        delete c;
-        return fail(nullptr, HCTR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
-    }
-    if (const char* bt = getenv("HCTR_BIG_TILES")) c->big_tiles = atoi(bt) != 0;
-    if (const char* hm = getenv("HCTR_HALO")) c->halo_mode = atoi(hm);
-    if (const char* pr = getenv("HCTR_PRECISION")) c->split = std::string(pr) == "f16x3";
-    if (const char* fs = getenv("HCTR_FUSE_SE")) c->fuse_se = atoi(fs) != 0;
-    if (const char* fa = getenv("HCTR_FUSE_ARGMAX")) c->fuse_argmax = atoi(fa) != 0;
-    if (const char* fd = getenv("HCTR_FUSE_DS")) c->fuse_ds = atoi(fd) != 0;
-    if (const char* wb = getenv("HCTR_WS_BUDGET_GB")) {
-        const long long v = atoll(wb);
-        if (v > 0) c->ws_budget = (size_t)v << 30;
-    }
-    if (const char* mc = getenv("HCTR_MAX_COLS")) {
-        const long long v = atoll(mc);
-        if (v > 0) c->max_cols = v;
-    }
-    *out = c;
-    return HCTR_OK;
+    return guard(nullptr, [&]() -> int {
+        if (!out) return fail(nullptr, HCTR_ERR_ARG, "out is NULL");
+        *out = nullptr;
+        if (num_classes < 3) return fail(nullptr, HCTR_ERR_ARG, "num_classes must be >= 3 (blank + chars + unknown)");
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0)
+            return fail(nullptr, HCTR_ERR_HIP, "no HIP device available (%s): the hctr engine has no CPU fallback",
+                        hipGetErrorString(e));
+        if (device < 0 || device >= ndev) return fail(nullptr, HCTR_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+        e = hipSetDevice(device);
+        if (e != hipSuccess) return fail(nullptr, HCTR_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        hctr_ctx* c = new hctr_ctx();
+        c->device = device;
+        c->num_classes = num_classes;
+        c->cpad = (num_classes + 255) / 256 * 256;
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return fail(nullptr, HCTR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+        if (const char* bt = getenv("HCTR_BIG_TILES")) c->big_tiles = atoi(bt) != 0;
+        if (const char* hm = getenv("HCTR_HALO")) c->halo_mode = atoi(hm);
+        if (const char* pr = getenv("HCTR_PRECISION")) c->split = std::string(pr) == "f16x3";
+        if (const char* fs = getenv("HCTR_FUSE_SE")) c->fuse_se = atoi(fs) != 0;
+        if (const char* fa = getenv("HCTR_FUSE_ARGMAX")) c->fuse_argmax = atoi(fa) != 0;
+        if (const char* fd = getenv("HCTR_FUSE_DS")) c->fuse_ds = atoi(fd) != 0;
+        if (const char* wb = getenv("HCTR_WS_BUDGET_GB")) {
+            const long long v = atoll(wb);
+            if (v > 0) c->ws_budget = (size_t)v << 30;
+        }
+        if (const char* mc = getenv("HCTR_MAX_COLS")) {
+            const long long v = atoll(mc);
+            if (v > 0) c->max_cols = v;
+        }
+        *out = c;
+        return HCTR_OK;
+    });
 }
 
 void hctr_destroy(hctr_ctx* c) {
@@ -723,69 +787,75 @@ void hctr_destroy(hctr_ctx* c) {
 const char* hctr_last_error(const hctr_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 int hctr_load_tensor(hctr_ctx* c, const char* key, const void* host_ptr, const int64_t* shape, int ndim, int dtype) {
-    if (!c) return HCTR_ERR_ARG;
-    if (!key || (!host_ptr && ndim > 0) || ndim < 0 || ndim > 8) return fail(c, HCTR_ERR_ARG, "bad tensor arguments");
-    if (c->finalized) return fail(c, HCTR_ERR_STATE, "weights already finalized");
-    const std::string k(key);
-    if (dtype == HCTR_I64) {       // num_batches_tracked: accepted, unused in eval mode
-        if (k.size() < 19 || k.compare(k.size() - 19, 19, "num_batches_tracked") != 0)
-            return fail(c, HCTR_ERR_KEY, "Unexpected key(s) in state_dict: \"%s\" (int64)", key);
+    return guard(c, [&]() -> int {
+        if (!c) return HCTR_ERR_ARG;
+        if (!key || (!host_ptr && ndim > 0) || ndim < 0 || ndim > 8) return fail(c, HCTR_ERR_ARG, "bad tensor arguments");
+        if (c->finalized) return fail(c, HCTR_ERR_STATE, "weights already finalized");
+        const std::string k(key);
+        if (dtype == HCTR_I64) {       // num_batches_tracked: accepted, unused in eval mode
+            if (k.size() < 19 || k.compare(k.size() - 19, 19, "num_batches_tracked") != 0)
+                return fail(c, HCTR_ERR_KEY, "Unexpected key(s) in state_dict: \"%s\" (int64)", key);
+            return HCTR_OK;
+        }
+        if (dtype != HCTR_F32) return fail(c, HCTR_ERR_ARG, "tensor %s: only float32 parameters are supported", key);
+        HostTensor t;
+        int64_t n = 1;
+        for (int i = 0; i < ndim; ++i) {
+            if (shape[i] < 0) return fail(c, HCTR_ERR_ARG, "negative dimension");
+            t.shape.push_back(shape[i]);
+            n *= shape[i];
+        }
+        t.data.assign((const float*)host_ptr, (const float*)host_ptr + n);
+        c->host[k] = std::move(t);
         return HCTR_OK;
-    }
-    if (dtype != HCTR_F32) return fail(c, HCTR_ERR_ARG, "tensor %s: only float32 parameters are supported", key);
-    HostTensor t;
-    int64_t n = 1;
-    for (int i = 0; i < ndim; ++i) {
-        if (shape[i] < 0) return fail(c, HCTR_ERR_ARG, "negative dimension");
-        t.shape.push_back(shape[i]);
-        n *= shape[i];
-    }
-    t.data.assign((const float*)host_ptr, (const float*)host_ptr + n);
-    c->host[k] = std::move(t);
-    return HCTR_OK;
+    });
 }
 
 int hctr_finalize_weights(hctr_ctx* c) {
-    if (!c) return HCTR_ERR_ARG;
-    if (c->finalized) return fail(c, HCTR_ERR_STATE, "weights already finalized");
-    HIP_TRY(c, hipSetDevice(c->device));
-    TRY(build_stem(c));
-    TRY(build_conv(c, "cnn.conv0_2", "cnn.bn0_2", 64, 64, 3, true, 64, &c->conv0_2));
-    int inpl = 64;
-    for (int s = 0; s < 4; ++s) {
-        const int planes = kStagePlanes[s];
-        c->blocks[s].resize(kStageBlocks[s]);
-        for (int i = 0; i < kStageBlocks[s]; ++i) {
-            BlockW& bw = c->blocks[s][i];
-            const std::string p = "cnn.block" + std::to_string(s + 1) + "." + std::to_string(i);
-            if (i == 0 && inpl != planes) {
-                bw.has_ds = true;
-                TRY(build_conv(c, p + ".downsample.0", p + ".downsample.1", inpl, planes, 1, false, 128, &bw.ds));
+    return guard(c, [&]() -> int {
+        if (!c) return HCTR_ERR_ARG;
+        if (c->finalized) return fail(c, HCTR_ERR_STATE, "weights already finalized");
+        HIP_TRY(c, hipSetDevice(c->device));
+        TRY(build_stem(c));
+        TRY(build_conv(c, "cnn.conv0_2", "cnn.bn0_2", 64, 64, 3, true, 64, &c->conv0_2));
+        int inpl = 64;
+        for (int s = 0; s < 4; ++s) {
+            const int planes = kStagePlanes[s];
+            c->blocks[s].resize(kStageBlocks[s]);
+            for (int i = 0; i < kStageBlocks[s]; ++i) {
+                BlockW& bw = c->blocks[s][i];
+                const std::string p = "cnn.block" + std::to_string(s + 1) + "." + std::to_string(i);
+                if (i == 0 && inpl != planes) {
+                    bw.has_ds = true;
+                    TRY(build_conv(c, p + ".downsample.0", p + ".downsample.1", inpl, planes, 1, false, 128, &bw.ds));
+                }
+                TRY(build_conv(c, p + ".conv1", p + ".bn1", inpl, planes, 3, true, 128, &bw.conv1));
+                TRY(build_conv(c, p + ".conv2", p + ".bn2", planes, planes, 3, true, 128, &bw.conv2));
+                TRY(build_se(c, p + ".se", planes, &bw.se));
+                inpl = planes;
             }
-            TRY(build_conv(c, p + ".conv1", p + ".bn1", inpl, planes, 3, true, 128, &bw.conv1));
-            TRY(build_conv(c, p + ".conv2", p + ".bn2", planes, planes, 3, true, 128, &bw.conv2));
-            TRY(build_se(c, p + ".se", planes, &bw.se));
-            inpl = planes;
+            const std::string k = "cnn.conv" + std::to_string(s + 1);
+            TRY(build_conv(c, k, "cnn.bn" + std::to_string(s + 1), planes, planes, 3, true, 128, &c->stage_conv[s]));
         }
-        const std::string k = "cnn.conv" + std::to_string(s + 1);
-        TRY(build_conv(c, k, "cnn.bn" + std::to_string(s + 1), planes, planes, 3, true, 128, &c->stage_conv[s]));
-    }
-    TRY(build_head(c));
-    // strict load: no unexpected float keys (load_state_dict(strict=True), test.py:153)
-    for (auto& kv : c->host)
-        if (!kv.second.used)
-            return fail(c, HCTR_ERR_KEY, "Unexpected key(s) in state_dict: \"%s\"", kv.first.c_str());
-    c->host.clear();
-    c->finalized = true;
-    return HCTR_OK;
+        TRY(build_head(c));
+        // strict load: no unexpected float keys (load_state_dict(strict=True), test.py:153)
+        for (auto& kv : c->host)
+            if (!kv.second.used)
+                return fail(c, HCTR_ERR_KEY, "Unexpected key(s) in state_dict: \"%s\"", kv.first.c_str());
+        c->host.clear();
+        c->finalized = true;
+        return HCTR_OK;
+    });
 }
 
 int hctr_set_precision(hctr_ctx* c, int mode) {
-    if (!c) return HCTR_ERR_ARG;
-    if (mode != 0 && mode != 1) return fail(c, HCTR_ERR_ARG, "precision mode must be 0 (f16) or 1 (f16x3)");
-    if (c->finalized) return fail(c, HCTR_ERR_STATE, "precision must be chosen before hctr_finalize_weights");
-    c->split = mode == 1;
-    return HCTR_OK;
+    return guard(c, [&]() -> int {
+        if (!c) return HCTR_ERR_ARG;
+        if (mode != 0 && mode != 1) return fail(c, HCTR_ERR_ARG, "precision mode must be 0 (f16) or 1 (f16x3)");
+        if (c->finalized) return fail(c, HCTR_ERR_STATE, "precision must be chosen before hctr_finalize_weights");
+        c->split = mode == 1;
+        return HCTR_OK;
+    });
 }
 
 int hctr_set_profiling(hctr_ctx* c, int enabled) {
@@ -795,436 +865,465 @@ int hctr_set_profiling(hctr_ctx* c, int enabled) {
 }
 
 int hctr_last_profile(hctr_ctx* c, char* names_buf, int cap, float* ms, int max_n) {
-    if (!c) return HCTR_ERR_ARG;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    std::string names;
-    std::vector<std::string> order;
-    int n = 0;
-    for (auto& pe : c->prof) {
-        float t = 0.f;
-        HIP_TRY(c, hipEventElapsedTime(&t, pe.e0, pe.e1));
-        size_t i = 0;
-        while (i < order.size() && order[i] != pe.name) ++i;      // internal passes repeat the layer names
-        if (i == order.size()) {
-            if (n >= max_n) break;
-            order.push_back(pe.name);
-            ms[n++] = 0.f;
-            names += pe.name;
-            names += '\n';
+    return guard(c, [&]() -> int {
+        if (!c) return HCTR_ERR_ARG;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::string names;
+        std::vector<std::string> order;
+        int n = 0;
+        for (auto& pe : c->prof) {
+            float t = 0.f;
+            HIP_TRY(c, hipEventElapsedTime(&t, pe.e0, pe.e1));
+            size_t i = 0;
+            while (i < order.size() && order[i] != pe.name) ++i;      // internal passes repeat the layer names
+            if (i == order.size()) {
+                if (n >= max_n) break;
+                order.push_back(pe.name);
+                ms[n++] = 0.f;
+                names += pe.name;
+                names += '\n';
+            }
+            ms[i] += t;
         }
-        ms[i] += t;
-    }
-    if (names_buf && cap > 0) {
-        strncpy(names_buf, names.c_str(), (size_t)cap - 1);
-        names_buf[cap - 1] = 0;
-    }
-    return n;
+        if (names_buf && cap > 0) {
+            strncpy(names_buf, names.c_str(), (size_t)cap - 1);
+            names_buf[cap - 1] = 0;
+        }
+        return n;
+    });
 }
 
 int hctr_forward_logits(hctr_ctx* c, const void* img, int img_dtype, int img_on_device, const int32_t* widths,
                         int B, int W, float* out_wbc, int out_on_device) {
-    TRY(check_forward_args(c, img, img_dtype, B, W));
-    if (!out_wbc) return fail(c, HCTR_ERR_ARG, "out_wbc is NULL");
-    if (B == 0) return HCTR_OK;
-    HIP_TRY(c, hipSetDevice(c->device));
-    const int C = c->num_classes;
-    const int nbmax = sub_batch(c, B, W);
-    prof_reset(c);
-    float* dev_out = out_wbc;
-    std::vector<void*> tmp;
-    if (!out_on_device) {
-        int r = dev_alloc(c, tmp, &dev_out, (size_t)B * W * C, false);
-        if (r != HCTR_OK) { free_pool(tmp); return r; }
-    }
-    int rc = HCTR_OK;
-    for (int b0 = 0; b0 < B && rc == HCTR_OK; b0 += nbmax) {
-        const int nb = std::min(nbmax, B - b0);
-        rc = ensure_workspace(c, nb, W);
-        if (rc == HCTR_OK) rc = stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W);
-        if (rc == HCTR_OK) rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr);
-        if (rc == HCTR_OK) {
-            // [nb*W][cpad] -> out[t][b0+b][C] with full-batch row stride
-            hipError_t e = launch_logits_to_wbc(c->ws.logits, c->cpad, nb, W, C, dev_out, B, b0, c->stream);
-            if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "logits_to_wbc: %s", hipGetErrorString(e));
+    return guard(c, [&]() -> int {
+        TRY(check_forward_args(c, img, img_dtype, B, W));
+        if (!out_wbc) return fail(c, HCTR_ERR_ARG, "out_wbc is NULL");
+        if (B == 0) return HCTR_OK;
+        HIP_TRY(c, hipSetDevice(c->device));
+        const int C = c->num_classes;
+        const int nbmax = sub_batch(c, B, W);
+        prof_reset(c);
+        float* dev_out = out_wbc;
+        std::vector<void*> tmp;
+        PoolGuard tmp_guard{tmp};
+        if (!out_on_device) {
+            int r = dev_alloc(c, tmp, &dev_out, (size_t)B * W * C, false);
+            if (r != HCTR_OK) { free_pool(tmp); return r; }
         }
-    }
-    if (rc == HCTR_OK && !out_on_device) {
-        hipError_t e = hipMemcpyAsync(out_wbc, dev_out, (size_t)B * W * C * 4, hipMemcpyDeviceToHost, c->stream);
-        if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "D2H logits: %s", hipGetErrorString(e));
-    }
-    hipError_t e = hipStreamSynchronize(c->stream);
-    if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
-    free_pool(tmp);
-    return rc;
+        int rc = HCTR_OK;
+        for (int b0 = 0; b0 < B && rc == HCTR_OK; b0 += nbmax) {
+            const int nb = std::min(nbmax, B - b0);
+            rc = ensure_workspace(c, nb, W);
+            if (rc == HCTR_OK) rc = stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W);
+            if (rc == HCTR_OK) rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr);
+            if (rc == HCTR_OK) {
+                // [nb*W][cpad] -> out[t][b0+b][C] with full-batch row stride
+                hipError_t e = launch_logits_to_wbc(c->ws.logits, c->cpad, nb, W, C, dev_out, B, b0, c->stream);
+                if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "logits_to_wbc: %s", hipGetErrorString(e));
+            }
+        }
+        if (rc == HCTR_OK && !out_on_device) {
+            hipError_t e = hipMemcpyAsync(out_wbc, dev_out, (size_t)B * W * C * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "D2H logits: %s", hipGetErrorString(e));
+        }
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
+        free_pool(tmp);
+        return rc;
+    });
 }
 
 int hctr_greedy(hctr_ctx* c, const void* img, int img_dtype, int img_on_device, const int32_t* widths, int B, int W,
                 int32_t* labels, int32_t* lengths) {
-    TRY(check_forward_args(c, img, img_dtype, B, W));
-    if (!labels || !lengths) return fail(c, HCTR_ERR_ARG, "labels/lengths is NULL");
-    if (B == 0) return HCTR_OK;
-    HIP_TRY(c, hipSetDevice(c->device));
-    const int C = c->num_classes;
-    const int nbmax = sub_batch(c, B, W);
-    prof_reset(c);
-    for (int b0 = 0; b0 < B; b0 += nbmax) {
-        const int nb = std::min(nbmax, B - b0);
-        TRY(ensure_workspace(c, nb, W));
-        TRY(stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W));
-        TRY(run_forward(c, img_dtype == HCTR_F32, widths != nullptr, c->fuse_argmax));
-        Workspace& ws = c->ws;
-        Prof pf(c);
-        if (!c->fuse_argmax) {
-            pf.begin("argmax_rows");
-            HIP_TRY(c, launch_argmax_rows(ws.logits, c->cpad, (int64_t)nb * W, C, ws.colidx, 0, 0, c->stream));
+    return guard(c, [&]() -> int {
+        TRY(check_forward_args(c, img, img_dtype, B, W));
+        if (!labels || !lengths) return fail(c, HCTR_ERR_ARG, "labels/lengths is NULL");
+        if (B == 0) return HCTR_OK;
+        HIP_TRY(c, hipSetDevice(c->device));
+        const int C = c->num_classes;
+        const int nbmax = sub_batch(c, B, W);
+        prof_reset(c);
+        // every pass queues async copies into the caller's buffers: on a failure the stream is still drained
+        // before returning, so nothing is in flight into (or out of) caller memory after an error
+        int rc = HCTR_OK;
+        auto pass = [&](int b0, int nb) -> int {
+            TRY(ensure_workspace(c, nb, W));
+            TRY(stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W));
+            TRY(run_forward(c, img_dtype == HCTR_F32, widths != nullptr, c->fuse_argmax));
+            Workspace& ws = c->ws;
+            Prof pf(c);
+            if (!c->fuse_argmax) {
+                pf.begin("argmax_rows");
+                HIP_TRY(c, launch_argmax_rows(ws.logits, c->cpad, (int64_t)nb * W, C, ws.colidx, 0, 0, c->stream));
+                pf.end();
+            }
+            pf.begin("ctc_collapse");
+            HIP_TRY(c, launch_ctc_collapse(ws.colidx, nb, W, C, ws.labels, ws.lengths, c->stream));
             pf.end();
-        }
-        pf.begin("ctc_collapse");
-        HIP_TRY(c, launch_ctc_collapse(ws.colidx, nb, W, C, ws.labels, ws.lengths, c->stream));
-        pf.end();
-        HIP_TRY(c, hipMemcpyAsync(labels + (size_t)b0 * W, ws.labels, (size_t)nb * W * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(lengths + b0, ws.lengths, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    return HCTR_OK;
+            HIP_TRY(c, hipMemcpyAsync(labels + (size_t)b0 * W, ws.labels, (size_t)nb * W * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(lengths + b0, ws.lengths, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+            return HCTR_OK;
+        };
+        for (int b0 = 0; b0 < B && rc == HCTR_OK; b0 += nbmax) rc = pass(b0, std::min(nbmax, B - b0));
+        const hipError_t es = hipStreamSynchronize(c->stream);
+        if (rc == HCTR_OK && es != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(es));
+        return rc;
+    });
 }
 
 int hctr_decode_greedy_logits(hctr_ctx* c, const float* logits_wbc, int on_device, int W, int B, int C,
                               int32_t* labels, int32_t* lengths) {
-    if (!c) return HCTR_ERR_ARG;
-    if (W < 0 || B < 0 || C < 2) return fail(c, HCTR_ERR_ARG, "bad logits shape W=%d B=%d C=%d", W, B, C);
-    if ((int64_t)W * B == 0) return HCTR_OK;     // reference: zero-length lines produce no output (:85-86)
-    if (!logits_wbc || !labels || !lengths) return fail(c, HCTR_ERR_ARG, "NULL pointer");
-    HIP_TRY(c, hipSetDevice(c->device));
-    std::vector<void*> tmp;
-    const size_t n = (size_t)W * B * C;
-    const float* dev = logits_wbc;
-    float* up = nullptr;
-    int32_t *idx = nullptr, *dl = nullptr, *dn = nullptr;
-    int rc = HCTR_OK;
-    if (!on_device) {
-        rc = dev_alloc(c, tmp, &up, n, false);
-        if (rc == HCTR_OK) {
-            hipError_t e = hipMemcpyAsync(up, logits_wbc, n * 4, hipMemcpyHostToDevice, c->stream);
-            if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "H2D logits: %s", hipGetErrorString(e));
+    return guard(c, [&]() -> int {
+        if (!c) return HCTR_ERR_ARG;
+        if (W < 0 || B < 0 || C < 2) return fail(c, HCTR_ERR_ARG, "bad logits shape W=%d B=%d C=%d", W, B, C);
+        if ((int64_t)W * B == 0) return HCTR_OK;     // reference: zero-length lines produce no output (:85-86)
+        if (!logits_wbc || !labels || !lengths) return fail(c, HCTR_ERR_ARG, "NULL pointer");
+        HIP_TRY(c, hipSetDevice(c->device));
+        std::vector<void*> tmp;
+        PoolGuard tmp_guard{tmp};
+        const size_t n = (size_t)W * B * C;
+        const float* dev = logits_wbc;
+        float* up = nullptr;
+        int32_t *idx = nullptr, *dl = nullptr, *dn = nullptr;
+        int rc = HCTR_OK;
+        if (!on_device) {
+            rc = dev_alloc(c, tmp, &up, n, false);
+            if (rc == HCTR_OK) {
+                hipError_t e = hipMemcpyAsync(up, logits_wbc, n * 4, hipMemcpyHostToDevice, c->stream);
+                if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "H2D logits: %s", hipGetErrorString(e));
+            }
+            dev = up;
         }
-        dev = up;
-    }
-    if (rc == HCTR_OK) rc = dev_alloc(c, tmp, &idx, (size_t)W * B, false);
-    if (rc == HCTR_OK) rc = dev_alloc(c, tmp, &dl, (size_t)W * B, false);
-    if (rc == HCTR_OK) rc = dev_alloc(c, tmp, &dn, (size_t)B, false);
-    if (rc == HCTR_OK) {
-        // rows of the WBC tensor are r = t*B + b; the argmax kernel writes idx as [b][t]
-        hipError_t e = launch_argmax_rows(dev, C, (int64_t)W * B, C, idx, B, W, c->stream);
-        if (e == hipSuccess) e = launch_ctc_collapse(idx, B, W, C, dl, dn, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(labels, dl, (size_t)W * B * 4, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(lengths, dn, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream);
-        if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "decode_greedy_logits: %s", hipGetErrorString(e));
-    }
-    hipError_t e = hipStreamSynchronize(c->stream);
-    if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
-    free_pool(tmp);
-    return rc;
+        if (rc == HCTR_OK) rc = dev_alloc(c, tmp, &idx, (size_t)W * B, false);
+        if (rc == HCTR_OK) rc = dev_alloc(c, tmp, &dl, (size_t)W * B, false);
+        if (rc == HCTR_OK) rc = dev_alloc(c, tmp, &dn, (size_t)B, false);
+        if (rc == HCTR_OK) {
+            // rows of the WBC tensor are r = t*B + b; the argmax kernel writes idx as [b][t]
+            hipError_t e = launch_argmax_rows(dev, C, (int64_t)W * B, C, idx, B, W, c->stream);
+            if (e == hipSuccess) e = launch_ctc_collapse(idx, B, W, C, dl, dn, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(labels, dl, (size_t)W * B * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(lengths, dn, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "decode_greedy_logits: %s", hipGetErrorString(e));
+        }
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
+        free_pool(tmp);
+        return rc;
+    });
 }
 
 int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_device, const int32_t* widths,
                        const float* logits_wbc, int logits_on_device, int B, int W, int C, int k,
                        int want_candidates, int32_t* topk_idx, float* topk_logp, float* blank_logp,
                        int64_t* num_candidates) {
-    if (!c) return HCTR_ERR_ARG;
-    if (B < 0 || W < 0 || k < 1) return fail(c, HCTR_ERR_ARG, "bad shape B=%d W=%d k=%d", B, W, k);
-    if (!topk_idx || !topk_logp || !blank_logp) return fail(c, HCTR_ERR_ARG, "NULL output pointer");
-    c->cand_off.assign((size_t)W * B + 1, 0);
-    c->cand_idx.clear();
-    c->cand_logp.clear();
-    if (num_candidates) *num_candidates = 0;
-    if ((int64_t)B * W == 0) return HCTR_OK;
-    HIP_TRY(c, hipSetDevice(c->device));
-    const bool from_img = img != nullptr;
-    if (from_img) {
-        TRY(check_forward_args(c, img, img_dtype, B, W));
-        if (C != c->num_classes) return fail(c, HCTR_ERR_ARG, "C=%d differs from the model's %d classes", C, c->num_classes);
-    } else if (!logits_wbc) {
-        return fail(c, HCTR_ERR_ARG, "neither img nor logits given");
-    }
-    if (k > C) return fail(c, HCTR_ERR_ARG, "k=%d exceeds C=%d", k, C);
-    const double thresh = std::log(0.001);        // utils/ctc_codec.py:128
-    const int nbmax = from_img ? sub_batch(c, B, W) : B;
-    prof_reset(c);
-    struct PassOut { int b0, nb; std::vector<int64_t> loff; std::vector<int32_t> ci; std::vector<float> cl; };
-    std::vector<PassOut> outs;
-    std::vector<int32_t> counts((size_t)W * B, 0);
-    std::vector<int32_t> h_idx, h_cnt;
-    std::vector<float> h_lp, h_bl;
-    std::vector<void*>& pool = c->beam_allocs;
-    int rc = HCTR_OK;
-    for (int b0 = 0; b0 < B && rc == HCTR_OK; b0 += nbmax) {
-        const int nb = std::min(nbmax, B - b0);
-        const int64_t rows = (int64_t)nb * W;
-        free_pool(pool);
-        const float* rowsrc = nullptr;
-        int64_t ld = 0;
+    return guard(c, [&]() -> int {
+        if (!c) return HCTR_ERR_ARG;
+        if (B < 0 || W < 0 || k < 1) return fail(c, HCTR_ERR_ARG, "bad shape B=%d W=%d k=%d", B, W, k);
+        if (!topk_idx || !topk_logp || !blank_logp) return fail(c, HCTR_ERR_ARG, "NULL output pointer");
+        c->cand_off.assign((size_t)W * B + 1, 0);
+        c->cand_idx.clear();
+        c->cand_logp.clear();
+        if (num_candidates) *num_candidates = 0;
+        if ((int64_t)B * W == 0) return HCTR_OK;
+        HIP_TRY(c, hipSetDevice(c->device));
+        const bool from_img = img != nullptr;
         if (from_img) {
-            rc = ensure_workspace(c, nb, W);
-            if (rc == HCTR_OK) rc = stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W);
-            if (rc == HCTR_OK) rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr);
-            rowsrc = c->ws.logits; ld = c->cpad;
-        } else {
-            float *up = nullptr, *rowsbuf = nullptr;
-            const float* dev = logits_wbc;
-            if (!logits_on_device) {
-                rc = dev_alloc(c, pool, &up, (size_t)rows * C, false);
-                if (rc == HCTR_OK) {
-                    hipError_t e = hipMemcpyAsync(up, logits_wbc, (size_t)rows * C * 4, hipMemcpyHostToDevice, c->stream);
-                    if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "H2D logits: %s", hipGetErrorString(e));
-                }
-                dev = up;
-            }
-            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &rowsbuf, (size_t)rows * C, false);
-            if (rc == HCTR_OK) {
-                hipError_t e = launch_wbc_to_rows(dev, nb, W, C, rowsbuf, C, c->stream);
-                if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "wbc_to_rows: %s", hipGetErrorString(e));
-            }
-            rowsrc = rowsbuf; ld = C;
+            TRY(check_forward_args(c, img, img_dtype, B, W));
+            if (C != c->num_classes) return fail(c, HCTR_ERR_ARG, "C=%d differs from the model's %d classes", C, c->num_classes);
+        } else if (!logits_wbc) {
+            return fail(c, HCTR_ERR_ARG, "neither img nor logits given");
         }
-        int32_t *d_idx = nullptr, *d_cnt = nullptr;
-        float *d_lp = nullptr, *d_bl = nullptr, *d_st = nullptr;
-        if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_idx, (size_t)rows * k, false);
-        if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_lp, (size_t)rows * k, false);
-        if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_bl, (size_t)rows, false);
-        if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_st, (size_t)rows * 2, false);
-        if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_cnt, (size_t)rows, false);
-        if (rc != HCTR_OK) break;
-        hipError_t e = launch_row_topk(rowsrc, ld, nb, W, C, k, thresh, d_idx, d_lp, d_bl, d_st, d_cnt, c->stream);
-        if (e != hipSuccess) { rc = fail(c, HCTR_ERR_HIP, "row_topk: %s (C=%d)", hipGetErrorString(e), C); break; }
-        h_idx.resize((size_t)rows * k); h_lp.resize((size_t)rows * k); h_bl.resize(rows); h_cnt.resize(rows);
-        e = hipMemcpyAsync(h_idx.data(), d_idx, (size_t)rows * k * 4, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_lp.data(), d_lp, (size_t)rows * k * 4, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_bl.data(), d_bl, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { rc = fail(c, HCTR_ERR_HIP, "beam D2H: %s", hipGetErrorString(e)); break; }
-        for (int t = 0; t < W; ++t)
-            for (int b = 0; b < nb; ++b) {
-                const size_t src = (size_t)t * nb + b, dst = (size_t)t * B + b0 + b;
-                memcpy(topk_idx + dst * k, h_idx.data() + src * k, (size_t)k * 4);
-                memcpy(topk_logp + dst * k, h_lp.data() + src * k, (size_t)k * 4);
-                blank_logp[dst] = h_bl[src];
-                counts[dst] = h_cnt[src];
-            }
-        if (!want_candidates) continue;
-        outs.emplace_back();
-        PassOut& po = outs.back();
-        po.b0 = b0; po.nb = nb;
-        po.loff.resize(rows + 1);
-        int64_t tot = 0;
-        for (int64_t r = 0; r < rows; ++r) { po.loff[r] = tot; tot += h_cnt[r]; }
-        po.loff[rows] = tot;
-        po.ci.resize(tot); po.cl.resize(tot);
-        int64_t* d_off = nullptr;
-        int32_t* d_ci = nullptr;
-        float* d_cl = nullptr;
-        rc = dev_alloc(c, pool, &d_off, (size_t)rows + 1, false);
-        if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_ci, (size_t)std::max<int64_t>(tot, 1), false);
-        if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_cl, (size_t)std::max<int64_t>(tot, 1), false);
-        if (rc != HCTR_OK) break;
-        e = hipMemcpyAsync(d_off, po.loff.data(), (size_t)(rows + 1) * 8, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = launch_row_candidates(rowsrc, ld, nb, W, C, thresh, d_st, d_off, d_ci, d_cl, c->stream);
-        if (e == hipSuccess && tot) e = hipMemcpyAsync(po.ci.data(), d_ci, (size_t)tot * 4, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && tot) e = hipMemcpyAsync(po.cl.data(), d_cl, (size_t)tot * 4, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { rc = fail(c, HCTR_ERR_HIP, "row_candidates: %s", hipGetErrorString(e)); break; }
-    }
-    (void)hipStreamSynchronize(c->stream);
-    free_pool(pool);
-    if (rc != HCTR_OK || !want_candidates) return rc;
-    // merge the per-pass lists into one CSR in (t*B + b) order, held by the context until fetched
-    int64_t tot = 0;
-    for (int64_t r = 0; r < (int64_t)W * B; ++r) { c->cand_off[r] = tot; tot += counts[r]; }
-    c->cand_off[(size_t)W * B] = tot;
-    c->cand_idx.resize(tot); c->cand_logp.resize(tot);
-    for (const PassOut& po : outs)
-        for (int t = 0; t < W; ++t)
-            for (int b = 0; b < po.nb; ++b) {
-                const size_t src = (size_t)t * po.nb + b, dst = (size_t)t * B + po.b0 + b;
-                const int64_t n = po.loff[src + 1] - po.loff[src];
-                if (n) {
-                    memcpy(c->cand_idx.data() + c->cand_off[dst], po.ci.data() + po.loff[src], (size_t)n * 4);
-                    memcpy(c->cand_logp.data() + c->cand_off[dst], po.cl.data() + po.loff[src], (size_t)n * 4);
+        if (k > C) return fail(c, HCTR_ERR_ARG, "k=%d exceeds C=%d", k, C);
+        const double thresh = std::log(0.001);        // utils/ctc_codec.py:128
+        const int nbmax = from_img ? sub_batch(c, B, W) : B;
+        prof_reset(c);
+        struct PassOut { int b0, nb; std::vector<int64_t> loff; std::vector<int32_t> ci; std::vector<float> cl; };
+        std::vector<PassOut> outs;
+        std::vector<int32_t> counts((size_t)W * B, 0);
+        std::vector<int32_t> h_idx, h_cnt;
+        std::vector<float> h_lp, h_bl;
+        std::vector<void*>& pool = c->beam_allocs;
+        int rc = HCTR_OK;
+        for (int b0 = 0; b0 < B && rc == HCTR_OK; b0 += nbmax) {
+            const int nb = std::min(nbmax, B - b0);
+            const int64_t rows = (int64_t)nb * W;
+            free_pool(pool);
+            const float* rowsrc = nullptr;
+            int64_t ld = 0;
+            if (from_img) {
+                rc = ensure_workspace(c, nb, W);
+                if (rc == HCTR_OK) rc = stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W);
+                if (rc == HCTR_OK) rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr);
+                rowsrc = c->ws.logits; ld = c->cpad;
+            } else {
+                float *up = nullptr, *rowsbuf = nullptr;
+                const float* dev = logits_wbc;
+                if (!logits_on_device) {
+                    rc = dev_alloc(c, pool, &up, (size_t)rows * C, false);
+                    if (rc == HCTR_OK) {
+                        hipError_t e = hipMemcpyAsync(up, logits_wbc, (size_t)rows * C * 4, hipMemcpyHostToDevice, c->stream);
+                        if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "H2D logits: %s", hipGetErrorString(e));
+                    }
+                    dev = up;
                 }
+                if (rc == HCTR_OK) rc = dev_alloc(c, pool, &rowsbuf, (size_t)rows * C, false);
+                if (rc == HCTR_OK) {
+                    hipError_t e = launch_wbc_to_rows(dev, nb, W, C, rowsbuf, C, c->stream);
+                    if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "wbc_to_rows: %s", hipGetErrorString(e));
+                }
+                rowsrc = rowsbuf; ld = C;
             }
-    if (num_candidates) *num_candidates = tot;
-    return HCTR_OK;
+            int32_t *d_idx = nullptr, *d_cnt = nullptr;
+            float *d_lp = nullptr, *d_bl = nullptr, *d_st = nullptr;
+            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_idx, (size_t)rows * k, false);
+            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_lp, (size_t)rows * k, false);
+            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_bl, (size_t)rows, false);
+            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_st, (size_t)rows * 2, false);
+            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_cnt, (size_t)rows, false);
+            if (rc != HCTR_OK) break;
+            hipError_t e = launch_row_topk(rowsrc, ld, nb, W, C, k, thresh, d_idx, d_lp, d_bl, d_st, d_cnt, c->stream);
+            if (e != hipSuccess) { rc = fail(c, HCTR_ERR_HIP, "row_topk: %s (C=%d)", hipGetErrorString(e), C); break; }
+            h_idx.resize((size_t)rows * k); h_lp.resize((size_t)rows * k); h_bl.resize(rows); h_cnt.resize(rows);
+            e = hipMemcpyAsync(h_idx.data(), d_idx, (size_t)rows * k * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(h_lp.data(), d_lp, (size_t)rows * k * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(h_bl.data(), d_bl, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { rc = fail(c, HCTR_ERR_HIP, "beam D2H: %s", hipGetErrorString(e)); break; }
+            for (int t = 0; t < W; ++t)
+                for (int b = 0; b < nb; ++b) {
+                    const size_t src = (size_t)t * nb + b, dst = (size_t)t * B + b0 + b;
+                    memcpy(topk_idx + dst * k, h_idx.data() + src * k, (size_t)k * 4);
+                    memcpy(topk_logp + dst * k, h_lp.data() + src * k, (size_t)k * 4);
+                    blank_logp[dst] = h_bl[src];
+                    counts[dst] = h_cnt[src];
+                }
+            if (!want_candidates) continue;
+            outs.emplace_back();
+            PassOut& po = outs.back();
+            po.b0 = b0; po.nb = nb;
+            po.loff.resize(rows + 1);
+            int64_t tot = 0;
+            for (int64_t r = 0; r < rows; ++r) { po.loff[r] = tot; tot += h_cnt[r]; }
+            po.loff[rows] = tot;
+            po.ci.resize(tot); po.cl.resize(tot);
+            int64_t* d_off = nullptr;
+            int32_t* d_ci = nullptr;
+            float* d_cl = nullptr;
+            rc = dev_alloc(c, pool, &d_off, (size_t)rows + 1, false);
+            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_ci, (size_t)std::max<int64_t>(tot, 1), false);
+            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_cl, (size_t)std::max<int64_t>(tot, 1), false);
+            if (rc != HCTR_OK) break;
+            e = hipMemcpyAsync(d_off, po.loff.data(), (size_t)(rows + 1) * 8, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = launch_row_candidates(rowsrc, ld, nb, W, C, thresh, d_st, d_off, d_ci, d_cl, c->stream);
+            if (e == hipSuccess && tot) e = hipMemcpyAsync(po.ci.data(), d_ci, (size_t)tot * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess && tot) e = hipMemcpyAsync(po.cl.data(), d_cl, (size_t)tot * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { rc = fail(c, HCTR_ERR_HIP, "row_candidates: %s", hipGetErrorString(e)); break; }
+        }
+        (void)hipStreamSynchronize(c->stream);
+        free_pool(pool);
+        if (rc != HCTR_OK || !want_candidates) return rc;
+        // merge the per-pass lists into one CSR in (t*B + b) order, held by the context until fetched
+        int64_t tot = 0;
+        for (int64_t r = 0; r < (int64_t)W * B; ++r) { c->cand_off[r] = tot; tot += counts[r]; }
+        c->cand_off[(size_t)W * B] = tot;
+        c->cand_idx.resize(tot); c->cand_logp.resize(tot);
+        for (const PassOut& po : outs)
+            for (int t = 0; t < W; ++t)
+                for (int b = 0; b < po.nb; ++b) {
+                    const size_t src = (size_t)t * po.nb + b, dst = (size_t)t * B + po.b0 + b;
+                    const int64_t n = po.loff[src + 1] - po.loff[src];
+                    if (n) {
+                        memcpy(c->cand_idx.data() + c->cand_off[dst], po.ci.data() + po.loff[src], (size_t)n * 4);
+                        memcpy(c->cand_logp.data() + c->cand_off[dst], po.cl.data() + po.loff[src], (size_t)n * 4);
+                    }
+                }
+        if (num_candidates) *num_candidates = tot;
+        return HCTR_OK;
+    });
 }
 
 int hctr_beam_fetch_candidates(hctr_ctx* c, int64_t* cand_off, int32_t* cand_idx, float* cand_logp) {
-    if (!c) return HCTR_ERR_ARG;
-    if (c->cand_off.empty()) return fail(c, HCTR_ERR_STATE, "no candidate lists: call hctr_beam_frontend(want_candidates=1)");
-    if (!cand_off) return fail(c, HCTR_ERR_ARG, "cand_off is NULL");
-    memcpy(cand_off, c->cand_off.data(), c->cand_off.size() * 8);
-    if (!c->cand_idx.empty()) {
-        if (!cand_idx || !cand_logp) return fail(c, HCTR_ERR_ARG, "cand_idx/cand_logp is NULL");
-        memcpy(cand_idx, c->cand_idx.data(), c->cand_idx.size() * 4);
-        memcpy(cand_logp, c->cand_logp.data(), c->cand_logp.size() * 4);
-    }
-    return HCTR_OK;
+    return guard(c, [&]() -> int {
+        if (!c) return HCTR_ERR_ARG;
+        if (c->cand_off.empty()) return fail(c, HCTR_ERR_STATE, "no candidate lists: call hctr_beam_frontend(want_candidates=1)");
+        if (!cand_off) return fail(c, HCTR_ERR_ARG, "cand_off is NULL");
+        memcpy(cand_off, c->cand_off.data(), c->cand_off.size() * 8);
+        if (!c->cand_idx.empty()) {
+            if (!cand_idx || !cand_logp) return fail(c, HCTR_ERR_ARG, "cand_idx/cand_logp is NULL");
+            memcpy(cand_idx, c->cand_idx.data(), c->cand_idx.size() * 4);
+            memcpy(cand_logp, c->cand_logp.data(), c->cand_logp.size() * 4);
+        }
+        return HCTR_OK;
+    });
 }
 
 int hctr_log_softmax(hctr_ctx* c, const float* logits_wbc, int on_device, int W, int B, int C, float* out_host) {
-    if (!c) return HCTR_ERR_ARG;
-    if (W < 0 || B < 0 || C < 1) return fail(c, HCTR_ERR_ARG, "bad shape");
-    const int64_t rows = (int64_t)W * B;
-    if (rows == 0) return HCTR_OK;
-    if (!logits_wbc || !out_host) return fail(c, HCTR_ERR_ARG, "NULL pointer");
-    HIP_TRY(c, hipSetDevice(c->device));
-    std::vector<void*> tmp;
-    const float* dev = logits_wbc;
-    float *up = nullptr, *y = nullptr;
-    int rc = HCTR_OK;
-    if (!on_device) {
-        rc = dev_alloc(c, tmp, &up, (size_t)rows * C, false);
-        if (rc == HCTR_OK) {
-            hipError_t e = hipMemcpyAsync(up, logits_wbc, (size_t)rows * C * 4, hipMemcpyHostToDevice, c->stream);
-            if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "H2D logits: %s", hipGetErrorString(e));
+    return guard(c, [&]() -> int {
+        if (!c) return HCTR_ERR_ARG;
+        if (W < 0 || B < 0 || C < 1) return fail(c, HCTR_ERR_ARG, "bad shape");
+        const int64_t rows = (int64_t)W * B;
+        if (rows == 0) return HCTR_OK;
+        if (!logits_wbc || !out_host) return fail(c, HCTR_ERR_ARG, "NULL pointer");
+        HIP_TRY(c, hipSetDevice(c->device));
+        std::vector<void*> tmp;
+        PoolGuard tmp_guard{tmp};
+        const float* dev = logits_wbc;
+        float *up = nullptr, *y = nullptr;
+        int rc = HCTR_OK;
+        if (!on_device) {
+            rc = dev_alloc(c, tmp, &up, (size_t)rows * C, false);
+            if (rc == HCTR_OK) {
+                hipError_t e = hipMemcpyAsync(up, logits_wbc, (size_t)rows * C * 4, hipMemcpyHostToDevice, c->stream);
+                if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "H2D logits: %s", hipGetErrorString(e));
+            }
+            dev = up;
         }
-        dev = up;
-    }
-    if (rc == HCTR_OK) rc = dev_alloc(c, tmp, &y, (size_t)rows * C, false);
-    if (rc == HCTR_OK) {
-        hipError_t e = launch_log_softmax_rows(dev, rows, C, y, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(out_host, y, (size_t)rows * C * 4, hipMemcpyDeviceToHost, c->stream);
-        if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "log_softmax: %s", hipGetErrorString(e));
-    }
-    hipError_t e = hipStreamSynchronize(c->stream);
-    if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
-    free_pool(tmp);
-    return rc;
+        if (rc == HCTR_OK) rc = dev_alloc(c, tmp, &y, (size_t)rows * C, false);
+        if (rc == HCTR_OK) {
+            hipError_t e = launch_log_softmax_rows(dev, rows, C, y, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_host, y, (size_t)rows * C * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "log_softmax: %s", hipGetErrorString(e));
+        }
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
+        free_pool(tmp);
+        return rc;
+    });
 }
 
 int hctr_resize_lines(hctr_ctx* c, const uint8_t* packed_src, int64_t packed_bytes, const int64_t* offsets,
                       const int32_t* heights, const int32_t* widths, const int32_t* channels, int n, int out_height,
                       const int32_t* out_widths, int out_W, uint8_t* out, int out_on_device) {
-    if (!c) return HCTR_ERR_ARG;
-    if (n < 0 || out_height < 1 || out_W < 0 || packed_bytes < 0) return fail(c, HCTR_ERR_ARG, "bad shape");
-    if (n == 0 || out_W == 0) return HCTR_OK;
-    if (!packed_src || !offsets || !heights || !widths || !channels || !out_widths || !out)
-        return fail(c, HCTR_ERR_ARG, "NULL pointer");
-    if (n > 65535) return fail(c, HCTR_ERR_ARG, "at most 65535 images per call");
-    std::vector<ResizeLine> lines((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        const int ch = channels[i];
-        if (ch != 1 && ch != 3 && ch != -3) return fail(c, HCTR_ERR_ARG, "image %d: channels must be 1, 3 (BGR) or -3 (RGB)", i);
-        if (heights[i] < 1 || widths[i] < 1) return fail(c, HCTR_ERR_SHAPE, "image %d: empty source", i);
-        // cv2.resize asserts !dsize.empty(): a line so narrow that int(128 * w / h) == 0 fails there too
-        if (out_widths[i] < 1) return fail(c, HCTR_ERR_SHAPE, "image %d: destination width %d < 1", i, out_widths[i]);
-        const int64_t bytes = (int64_t)heights[i] * widths[i] * (ch < 0 ? -ch : ch);
-        if (offsets[i] < 0 || offsets[i] + bytes > packed_bytes)
-            return fail(c, HCTR_ERR_ARG, "image %d: [%lld, +%lld) outside the packed buffer of %lld bytes", i,
-                        (long long)offsets[i], (long long)bytes, (long long)packed_bytes);
-        ResizeLine& L = lines[(size_t)i];
-        L.src_off = offsets[i];
-        L.sh = heights[i];
-        L.sw = widths[i];
-        L.ch = ch;
-        L.dw = out_widths[i];
-        // dispatch of cv::resize for INTER_AREA (oracle/resize_ref.py resize_area)
-        L.inv_x = (double)L.dw / (double)L.sw;
-        L.inv_y = (double)out_height / (double)L.sh;
-        L.scale_x = 1.0 / L.inv_x;
-        L.scale_y = 1.0 / L.inv_y;
-        L.ix = (int)std::nearbyint(L.scale_x);
-        L.iy = (int)std::nearbyint(L.scale_y);
-        if (L.scale_x >= 1.0 && L.scale_y >= 1.0) {
-            const bool fast = std::fabs(L.scale_x - L.ix) < DBL_EPSILON && std::fabs(L.scale_y - L.iy) < DBL_EPSILON;
-            L.mode = fast ? 1 : 0;
-        } else {
-            L.mode = 2;
+    return guard(c, [&]() -> int {
+        if (!c) return HCTR_ERR_ARG;
+        if (n < 0 || out_height < 1 || out_W < 0 || packed_bytes < 0) return fail(c, HCTR_ERR_ARG, "bad shape");
+        if (n == 0 || out_W == 0) return HCTR_OK;
+        if (!packed_src || !offsets || !heights || !widths || !channels || !out_widths || !out)
+            return fail(c, HCTR_ERR_ARG, "NULL pointer");
+        if (n > 65535) return fail(c, HCTR_ERR_ARG, "at most 65535 images per call");
+        std::vector<ResizeLine> lines((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            const int ch = channels[i];
+            if (ch != 1 && ch != 3 && ch != -3) return fail(c, HCTR_ERR_ARG, "image %d: channels must be 1, 3 (BGR) or -3 (RGB)", i);
+            if (heights[i] < 1 || widths[i] < 1) return fail(c, HCTR_ERR_SHAPE, "image %d: empty source", i);
+            // cv2.resize asserts !dsize.empty(): a line so narrow that int(128 * w / h) == 0 fails there too
+            if (out_widths[i] < 1) return fail(c, HCTR_ERR_SHAPE, "image %d: destination width %d < 1", i, out_widths[i]);
+            const int64_t bytes = (int64_t)heights[i] * widths[i] * (ch < 0 ? -ch : ch);
+            if (offsets[i] < 0 || offsets[i] + bytes > packed_bytes)
+                return fail(c, HCTR_ERR_ARG, "image %d: [%lld, +%lld) outside the packed buffer of %lld bytes", i,
+                            (long long)offsets[i], (long long)bytes, (long long)packed_bytes);
+            ResizeLine& L = lines[(size_t)i];
+            L.src_off = offsets[i];
+            L.sh = heights[i];
+            L.sw = widths[i];
+            L.ch = ch;
+            L.dw = out_widths[i];
+            // dispatch of cv::resize for INTER_AREA (oracle/resize_ref.py resize_area)
+            L.inv_x = (double)L.dw / (double)L.sw;
+            L.inv_y = (double)out_height / (double)L.sh;
+            L.scale_x = 1.0 / L.inv_x;
+            L.scale_y = 1.0 / L.inv_y;
+            L.ix = (int)std::nearbyint(L.scale_x);
+            L.iy = (int)std::nearbyint(L.scale_y);
+            if (L.scale_x >= 1.0 && L.scale_y >= 1.0) {
+                const bool fast = std::fabs(L.scale_x - L.ix) < DBL_EPSILON && std::fabs(L.scale_y - L.iy) < DBL_EPSILON;
+                L.mode = fast ? 1 : 0;
+            } else {
+                L.mode = 2;
+            }
         }
-    }
-    HIP_TRY(c, hipSetDevice(c->device));
-    std::vector<void*> tmp;
-    uint8_t *src = nullptr, *dst = nullptr;
-    ResizeLine* dl = nullptr;
-    int rc = dev_alloc(c, tmp, &src, (size_t)std::max<int64_t>(packed_bytes, 1), false);
-    if (rc == HCTR_OK) rc = dev_alloc(c, tmp, &dl, (size_t)n, false);
-    const size_t out_bytes = (size_t)n * out_height * out_W;
-    if (rc == HCTR_OK && !out_on_device) rc = dev_alloc(c, tmp, &dst, out_bytes, false);
-    if (rc == HCTR_OK) {
-        uint8_t* target = out_on_device ? out : dst;
-        hipError_t e = hipMemcpyAsync(src, packed_src, (size_t)packed_bytes, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(dl, lines.data(), sizeof(ResizeLine) * (size_t)n, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = launch_resize_lines(src, dl, n, target, out_height, out_W, c->stream);
-        if (e == hipSuccess && !out_on_device)
-            e = hipMemcpyAsync(out, dst, out_bytes, hipMemcpyDeviceToHost, c->stream);
-        if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "resize_lines: %s", hipGetErrorString(e));
-    }
-    hipError_t e = hipStreamSynchronize(c->stream);
-    if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
-    free_pool(tmp);
-    return rc;
+        HIP_TRY(c, hipSetDevice(c->device));
+        std::vector<void*> tmp;
+        PoolGuard tmp_guard{tmp};
+        uint8_t *src = nullptr, *dst = nullptr;
+        ResizeLine* dl = nullptr;
+        int rc = dev_alloc(c, tmp, &src, (size_t)std::max<int64_t>(packed_bytes, 1), false);
+        if (rc == HCTR_OK) rc = dev_alloc(c, tmp, &dl, (size_t)n, false);
+        const size_t out_bytes = (size_t)n * out_height * out_W;
+        if (rc == HCTR_OK && !out_on_device) rc = dev_alloc(c, tmp, &dst, out_bytes, false);
+        if (rc == HCTR_OK) {
+            uint8_t* target = out_on_device ? out : dst;
+            hipError_t e = hipMemcpyAsync(src, packed_src, (size_t)packed_bytes, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(dl, lines.data(), sizeof(ResizeLine) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = launch_resize_lines(src, dl, n, target, out_height, out_W, c->stream);
+            if (e == hipSuccess && !out_on_device)
+                e = hipMemcpyAsync(out, dst, out_bytes, hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "resize_lines: %s", hipGetErrorString(e));
+        }
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
+        free_pool(tmp);
+        return rc;
+    });
 }
 
 int64_t hctr_debug_stamps(hctr_ctx* c, const char* layer, uint64_t* out, int64_t cap_wgs) {
-    if (!c || cap_wgs < 0) return HCTR_ERR_ARG;
-    if (hipSetDevice(c->device) != hipSuccess) return fail(c, HCTR_ERR_HIP, "hipSetDevice");
-    if (layer) {                                  // arm: later forwards stamp this layer's workgroups
-        if (c->stamp_buf) { (void)hipFree(c->stamp_buf); c->stamp_buf = nullptr; }
-        c->stamp_layer = layer;
-        c->stamp_cap = cap_wgs;
-        c->stamp_n = 0;
-        if (cap_wgs > 0 && hipMalloc((void**)&c->stamp_buf, (size_t)cap_wgs * 128) != hipSuccess)
-            return fail(c, HCTR_ERR_NOMEM, "stamp buffer");
-        return 0;
-    }
-    if (!out || !c->stamp_buf) return fail(c, HCTR_ERR_STATE, "stamping not armed");
-    const int64_t n = std::min(c->stamp_n, cap_wgs);
-    if (hipMemcpy(out, c->stamp_buf, (size_t)n * 128, hipMemcpyDeviceToHost) != hipSuccess)
-        return fail(c, HCTR_ERR_HIP, "stamp copy");
-    return n;
+    return guard<int64_t>(c, [&]() -> int64_t {
+        if (!c || cap_wgs < 0) return HCTR_ERR_ARG;
+        if (hipSetDevice(c->device) != hipSuccess) return fail(c, HCTR_ERR_HIP, "hipSetDevice");
+        if (layer) {                                  // arm: later forwards stamp this layer's workgroups
+            if (c->stamp_buf) { (void)hipFree(c->stamp_buf); c->stamp_buf = nullptr; }
+            c->stamp_layer = layer;
+            c->stamp_cap = cap_wgs;
+            c->stamp_n = 0;
+            if (cap_wgs > 0 && hipMalloc((void**)&c->stamp_buf, (size_t)cap_wgs * 128) != hipSuccess)
+                return fail(c, HCTR_ERR_NOMEM, "stamp buffer");
+            return 0;
+        }
+        if (!out || !c->stamp_buf) return fail(c, HCTR_ERR_STATE, "stamping not armed");
+        const int64_t n = std::min(c->stamp_n, cap_wgs);
+        if (hipMemcpy(out, c->stamp_buf, (size_t)n * 128, hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(c, HCTR_ERR_HIP, "stamp copy");
+        return n;
+    });
 }
 
 int64_t hctr_debug_activation(hctr_ctx* c, const char* name, float* out, int64_t cap, int* Cout, int* Hout) {
-    if (!c || !name) return HCTR_ERR_ARG;
-    const Workspace& ws = c->ws;
-    if (ws.B == 0) return fail(c, HCTR_ERR_STATE, "no forward has run");
-    const half_t* p = nullptr;
-    int H = 0, C = 0;
-    bool head = false;
-    const std::string n(name);
-    if (n == "conv0_1") { p = ws.s0; H = 128; C = 64; }
-    else if (n == "stage0") { p = ws.x[1]; H = 64; C = 64; }
-    else if (n == "stage1") { p = ws.x[2]; H = 32; C = 128; }
-    else if (n == "stage2") { p = ws.x[3]; H = 16; C = 256; }
-    else if (n == "stage3") { p = ws.x[4]; H = 8; C = 512; }
-    else if (n == "stage4") { p = ws.headin; H = 4; C = 512; head = true; }
-    else if (n.size() == 4 && n[0] == 'p' && n[2] == '.' && n[1] >= '1' && n[1] <= '4' && n[3] >= '0' && n[3] <= '2') {
-        // raw rotating block buffer i of stage s ("p<s>.<i>"): what it holds depends on the block count
-        const int st = n[1] - '0', bi = n[3] - '0';
-        p = ws.p[st][bi]; H = kStageH[st]; C = kStagePlanes[st - 1];
-        if (!p) return fail(c, HCTR_ERR_ARG, "buffer %s not allocated", name);
-    }
-    else return fail(c, HCTR_ERR_ARG, "unknown activation '%s'", name);
-    const int64_t total = (int64_t)ws.B * C * H * ws.W;
-    if (Cout) *Cout = C;
-    if (Hout) *Hout = H;
-    if (!out || cap < total) return total;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const int m = c->chm();                        // [hi | lo | hi] planes in f16x3 mode: report hi + lo
-    const int64_t elems = head ? (int64_t)ws.B * ws.W * kFeat * m : act_elems(ws.B, H, ws.Wa, C * m);
-    std::vector<half_t> host((size_t)elems);
-    HIP_TRY(c, hipMemcpy(host.data(), p, (size_t)elems * sizeof(half_t), hipMemcpyDeviceToHost));
-    for (int b = 0; b < ws.B; ++b)
-        for (int ch = 0; ch < C; ++ch)
-            for (int h = 0; h < H; ++h)
-                for (int w = 0; w < ws.W; ++w) {
-                    const int64_t src = head ? (((int64_t)b * ws.W + w) * 4 + h) * (512 * m) + ch
-                                             : (((int64_t)b * (H + 2) + h + 1) * ws.Wa + w + 1) * (C * m) + ch;
-                    float v = (float)host[(size_t)src];
-                    if (m == 3) v += (float)host[(size_t)src + C];
-                    out[(((int64_t)b * C + ch) * H + h) * ws.W + w] = v;
-                }
-    return total;
+    return guard<int64_t>(c, [&]() -> int64_t {
+        if (!c || !name) return HCTR_ERR_ARG;
+        const Workspace& ws = c->ws;
+        if (ws.B == 0) return fail(c, HCTR_ERR_STATE, "no forward has run");
+        const half_t* p = nullptr;
+        int H = 0, C = 0;
+        bool head = false;
+        const std::string n(name);
+        if (n == "conv0_1") { p = ws.s0; H = 128; C = 64; }
+        else if (n == "stage0") { p = ws.x[1]; H = 64; C = 64; }
+        else if (n == "stage1") { p = ws.x[2]; H = 32; C = 128; }
+        else if (n == "stage2") { p = ws.x[3]; H = 16; C = 256; }
+        else if (n == "stage3") { p = ws.x[4]; H = 8; C = 512; }
+        else if (n == "stage4") { p = ws.headin; H = 4; C = 512; head = true; }
+        else if (n.size() == 4 && n[0] == 'p' && n[2] == '.' && n[1] >= '1' && n[1] <= '4' && n[3] >= '0' && n[3] <= '2') {
+            // raw rotating block buffer i of stage s ("p<s>.<i>"): what it holds depends on the block count
+            const int st = n[1] - '0', bi = n[3] - '0';
+            p = ws.p[st][bi]; H = kStageH[st]; C = kStagePlanes[st - 1];
+            if (!p) return fail(c, HCTR_ERR_ARG, "buffer %s not allocated", name);
+        }
+        else return fail(c, HCTR_ERR_ARG, "unknown activation '%s'", name);
+        const int64_t total = (int64_t)ws.B * C * H * ws.W;
+        if (Cout) *Cout = C;
+        if (Hout) *Hout = H;
+        if (!out || cap < total) return total;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const int m = c->chm();                        // [hi | lo | hi] planes in f16x3 mode: report hi + lo
+        const int64_t elems = head ? (int64_t)ws.B * ws.W * kFeat * m : act_elems(ws.B, H, ws.Wa, C * m);
+        std::vector<half_t> host((size_t)elems);
+        HIP_TRY(c, hipMemcpy(host.data(), p, (size_t)elems * sizeof(half_t), hipMemcpyDeviceToHost));
+        for (int b = 0; b < ws.B; ++b)
+            for (int ch = 0; ch < C; ++ch)
+                for (int h = 0; h < H; ++h)
+                    for (int w = 0; w < ws.W; ++w) {
+                        const int64_t src = head ? (((int64_t)b * ws.W + w) * 4 + h) * (512 * m) + ch
+                                                 : (((int64_t)b * (H + 2) + h + 1) * ws.Wa + w + 1) * (C * m) + ch;
+                        float v = (float)host[(size_t)src];
+                        if (m == 3) v += (float)host[(size_t)src + C];
+                        out[(((int64_t)b * C + ch) * H + h) * ws.W + w] = v;
+                    }
+        return total;
+    });
 }
 
 }  // extern "C"

@@ -16,6 +16,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <limits>
+#include <memory>
+#include <new>
 #include <sstream>
 #include <string>
 #include <unordered_map>
@@ -86,12 +89,29 @@ extern "C" {
 
 const char* hctr_ngram_last_error(void) { return g_ngram_error.c_str(); }
 
+// No C++ exception crosses the ABI (include/hctr_hip.h): the loaders and scorers below catch everything; an
+// allocation failure while reading a model is HCTR_ERR_NOMEM, while scoring it is a NaN score / word id -1.
+static int ngram_load_impl(const char* arpa_path, hctr_ngram** out);
+
 int hctr_ngram_load(const char* arpa_path, hctr_ngram** out) {
-    if (!arpa_path || !out) { g_ngram_error = "NULL argument"; return HCTR_ERR_ARG; }
+    if (!arpa_path || !out) return HCTR_ERR_ARG;
     *out = nullptr;
+    try {
+        return ngram_load_impl(arpa_path, out);
+    } catch (const std::bad_alloc&) {
+        try { g_ngram_error = "out of host memory while reading the ARPA file"; } catch (...) {}
+        return HCTR_ERR_NOMEM;
+    } catch (...) {
+        try { g_ngram_error = "unexpected C++ exception while reading the ARPA file"; } catch (...) {}
+        return HCTR_ERR_STATE;
+    }
+}
+
+static int ngram_load_impl(const char* arpa_path, hctr_ngram** out) {
     std::ifstream f(arpa_path);
     if (!f) { g_ngram_error = std::string("cannot open ARPA file: ") + arpa_path; return HCTR_ERR_ARG; }
-    hctr_ngram* lm = new hctr_ngram();
+    std::unique_ptr<hctr_ngram> holder(new hctr_ngram());
+    hctr_ngram* lm = holder.get();
     std::string line;
     int section = 0;                                    // 0 = header, n = inside \n-grams:
     bool saw_data = false;
@@ -111,7 +131,6 @@ int hctr_ngram_load(const char* arpa_path, hctr_ngram** out) {
                 continue;
             }
             g_ngram_error = "unrecognised ARPA section at line " + std::to_string(lineno);
-            delete lm;
             return HCTR_ERR_ARG;
         }
         if (section == 0) continue;                      // "ngram N=count" lines
@@ -122,7 +141,6 @@ int hctr_ngram_load(const char* arpa_path, hctr_ngram** out) {
         while (ss >> t) tok.push_back(t);
         if ((int)tok.size() != section + 1 && (int)tok.size() != section + 2) {
             g_ngram_error = "malformed " + std::to_string(section) + "-gram at line " + std::to_string(lineno);
-            delete lm;
             return HCTR_ERR_ARG;
         }
         hctr_ngram::Entry e;
@@ -134,14 +152,13 @@ int hctr_ngram_load(const char* arpa_path, hctr_ngram** out) {
     }
     if (!saw_data || lm->order == 0) {
         g_ngram_error = std::string("not an ARPA file (no \\data\\ / n-gram sections): ") + arpa_path;
-        delete lm;
         return HCTR_ERR_ARG;
     }
     auto find = [&](const char* w) { auto it = lm->vocab.find(w); return it == lm->vocab.end() ? -1 : it->second; };
     lm->bos = find("<s>");
     lm->eos = find("</s>");
     lm->unk = find("<unk>");
-    *out = lm;
+    *out = holder.release();
     return HCTR_OK;
 }
 
@@ -151,13 +168,27 @@ int hctr_ngram_order(const hctr_ngram* lm) { return lm ? lm->order : 0; }
 
 int32_t hctr_ngram_word_id(const hctr_ngram* lm, const char* word_utf8) {
     if (!lm || !word_utf8) return -1;
-    auto it = lm->vocab.find(word_utf8);
-    return it == lm->vocab.end() ? -1 : it->second;
+    try {
+        auto it = lm->vocab.find(word_utf8);
+        return it == lm->vocab.end() ? -1 : it->second;
+    } catch (...) {
+        return -1;
+    }
 }
 
 // kenlm.Model.score(sentence, bos, eos): log10 probability of a whitespace-separated sentence
+static double ngram_score_impl(const hctr_ngram* lm, const char* sentence_utf8, int bos, int eos);
+
 double hctr_ngram_score(const hctr_ngram* lm, const char* sentence_utf8, int bos, int eos) {
     if (!lm || !sentence_utf8) return 0.0;
+    try {
+        return ngram_score_impl(lm, sentence_utf8, bos, eos);
+    } catch (...) {
+        return std::numeric_limits<double>::quiet_NaN();
+    }
+}
+
+static double ngram_score_impl(const hctr_ngram* lm, const char* sentence_utf8, int bos, int eos) {
     std::vector<int32_t> ctx;
     if (bos && lm->bos >= 0) ctx.push_back(lm->bos);
     double total = 0.0;

@@ -337,3 +337,23 @@ def test_header_and_c_example_compile_as_c99(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(tmp_path / "greedy_demo")], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr          # runs (no GPU needed to print usage)
+
+
+def test_abi_no_exception_crosses():
+    """include/hctr_hip.h: "no C++ exception crosses the ABI". A child process lowers RLIMIT_AS so that heap growth
+    (std::bad_alloc in the prefix trie) and thread creation (std::system_error) fail inside hctr_beam_search: the call
+    must come back with HCTR_ERR_NOMEM instead of ending the process through std::terminate; with room it succeeds."""
+    child = os.path.join(ROOT, "tests", "abi_guard_child.py")
+
+    def run(headroom_mb, threads):
+        r = subprocess.run([sys.executable, child, str(headroom_mb), str(threads)], capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, (headroom_mb, threads, r.returncode, r.stderr[-400:])
+        m = re.search(r"RC (-?\d+) LEN (\d+)", r.stdout)
+        assert m, r.stdout
+        return int(m.group(1)), int(m.group(2))
+
+    assert run(4, 1) == (-7, 0)            # HCTR_ERR_NOMEM from the search's own allocations
+    assert run(4, 8)[0] == -7              # no room for a thread stack either: falls back to the caller's thread
+    rc, total = run(4096, 8)
+    assert rc == 0 and total > 0
