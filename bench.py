@@ -4,10 +4,13 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path (NormalizePAD -> hctr trunk -> head -> argmax -> CTC collapse ->
-labels on the host, + one RCCL gather to rank 0 when N > 1) over one batch of synthetic line images
-per GPU: BASELINE.json configs[1], B=64 lines of 1x128x2000 per GPU, greedy decode. Inputs are
-uint8 images already resident in HBM when the timed region starts. Weak scaling: per-GPU work is
-fixed, value = all ranks' lines / max-over-ranks time.
+labels on the host, + one RCCL gather to rank 0 when N > 1) over one batch of synthetic line images.
+N = 1: BASELINE.json configs[1], B=64 lines of 1x128x2000, greedy decode. N > 1: configs[3], a FIXED
+global batch of 4096 lines cut into contiguous shards of 4096/N (strong scaling), every rank's labels
+gathered to rank 0 once per step. Inputs are uint8 images already resident in HBM when the timed region
+starts; value = global lines / max-over-ranks time. At N = 1 both precision modes are timed in the same
+run (`value` = --precision, default f16; `value_f16x3`) and their decoded text is compared with the
+REAL reference's greedy strings for all 64 lines (tests/golden/c2_lines.json).
 
 Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel, HIP events on the engine's own
 stream during the timed steps) and `cpu_baseline` (the oracle restatement on the host cores, bounded
@@ -25,8 +28,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W_LINE = 2000
-B_PER_GPU = 64
+B_PER_GPU = 64                        # BASELINE configs[1]: the 1-GPU workload
 SEED = 2
+B_GLOBAL_C4 = 4096                    # BASELINE configs[3]: the global batch sharded over N > 1 GPUs (strong scaling)
+SEED_C4 = 4
 FLOP_PER_COL_DOM = 75.497472e6        # one 3x3 512->512 @ H=16 layer, per pixel column
 FLOP_PER_COL_ALL = 1358.838912e6      # whole forward per pixel column at C=7358
 PEAK_F16_TFLOPS = 2500.0              # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
@@ -36,23 +41,67 @@ DOMINANT = tuple(n + sfx for n in ("block3.0.conv2", "block3.1.conv2", "block3.2
     ("block3.1.conv1", "block3.2.conv1", "block3.3.conv1", "block3.4.conv1", "conv3+pool")
 
 
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def load_c2_golden():
+    """REAL-reference outputs for the 64 lines of config 2 (tests/golden/make_golden_c2.py): greedy strings,
+    per-column argmax and top-1/top-2 margin of the fp32 CPU logits."""
+    gdir = os.path.join(ROOT, "tests", "golden")
+    with open(os.path.join(gdir, "c2_lines.json")) as f:
+        meta = json.load(f)
+    z = np.load(os.path.join(gdir, "c2_lines.npz"))
+    return meta, {k: z[k] for k in z.files}
+
+
+def edit_distance(a, b):
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def text_parity(texts, meta, n):
+    ref = meta["greedy"][:n]
+    return {"lines": n, "exact_lines": int(sum(a == b for a, b in zip(texts, ref))),
+            "char_edits": int(sum(edit_distance(a, b) for a, b in zip(texts, ref))),
+            "ref_chars": int(sum(len(s) for s in ref)),
+            "source": "tests/golden/c2_lines.json: REAL reference (fp32 CPU) greedy strings of these same lines"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="lines per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="lines per step (default: 64 at 1 GPU, 4096 globally at N > 1)")
     ap.add_argument("--width", type=int, default=W_LINE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-lines", type=int, default=2)
+    ap.add_argument("--cpu-lines", type=int, default=4, help="lines of the CPU baseline batch (BASELINE.md section 4: 4)")
     ap.add_argument("--layers", action="store_true", help="print the per-layer device-time table to stderr")
     ap.add_argument("--layer-file", default="", help="write the per-step launch order (layer names) to this file")
     ap.add_argument("--precision", default="f16", choices=["f16", "f16x3"],
-                    help="engine precision mode for the timed run (default f16; f16x3 = split hi+lo pairs)")
+                    help="engine precision mode of the headline timing (default f16; f16x3 = split hi+lo pairs)")
+    ap.add_argument("--no-second-mode", action="store_true",
+                    help="1 GPU: do not also time the other precision mode (profiling runs)")
+    ap.add_argument("--checkpoint", default="random", choices=["random", "trained"],
+                    help="synthetic checkpoint: near-tie-rich random head (default) or the trained-like head")
     ap.add_argument("--no-pipeline", action="store_true", help="c5: run front end and host search back to back")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"],
-                    help="c2 (default, the driver's line): B=64 x W=2000 greedy; c3: B=512 mixed widths "
-                         "{800,1600,2400,3200} bucketed; c5: B=256 x W=2000 beam search 10/10 (extra modes, 1 GPU)")
+                    help="c2 (default, the driver's line): B=64 x W=2000 greedy at 1 GPU, configs[3] (B=4096 sharded) "
+                         "at N > 1; c3: B=512 mixed widths {800,1600,2400,3200} bucketed; c5: B=256 x W=2000 beam "
+                         "search 10/10 (extra modes, 1 GPU)")
     args = ap.parse_args()
 
     import torch
@@ -80,48 +129,78 @@ def main():
     dev = torch.device("cuda", local)
 
     C = synth.DEFAULT_VOCAB + 2
-    B, W = args.batch, args.width
-    sd = synth.make_state_dict(C, seed=0)
+    W = args.width
+    sd = make_checkpoint(synth, C, args.checkpoint)
     model = hctr_amd.hctr_model(C, precision=args.precision).cuda(local)
     model.load_state_dict(sd)
     model.eval()
     if args.config != "c2":
         return extra_config(args, hctr_amd, model, sd, dev)
-    # this rank's contiguous shard of the global synthetic batch (seed, global line index)
-    imgs_host = synth.make_line_images(B, W, SEED, line_offset=rank * B)
+    import importlib
+    hdist = importlib.import_module(hctr_amd.package.__name__ + ".dist")
+
+    # N = 1: BASELINE configs[1], 64 lines. N > 1: BASELINE configs[3], a FIXED global batch of 4096 lines cut into
+    # contiguous shards (strong scaling): rank r owns lines [lo, hi) of the global synthetic batch (seed, line index).
+    if world == 1:
+        n_global = args.batch or B_PER_GPU
+        seed, cfg_name = SEED, "BASELINE configs[1]"
+    else:
+        n_global = args.batch or B_GLOBAL_C4
+        seed, cfg_name = SEED_C4, "BASELINE configs[3]"
+    lo, hi = hdist.shard_range(n_global, rank, world)
+    B = hi - lo
+    imgs_host = make_lines(synth, args.checkpoint, B, W, seed, lo)
     imgs = torch.from_numpy(imgs_host).to(dev)              # resident in HBM before timing
     torch.cuda.synchronize(dev)
-    n_global = B * world
-    import importlib
-    gather = importlib.import_module(hctr_amd.package.__name__ + ".dist").gather_labels
 
-    def step():
-        labels = model.greedy(imgs)
+    t_fwd, t_gather = [0.0], [0.0]
+
+    def step(m=model):
+        t0 = time.perf_counter()
+        labels = m.greedy(imgs)                              # synchronous at return (labels on the host)
+        t1 = time.perf_counter()
+        t_fwd[0] += t1 - t0
         if dist is not None:
-            return gather(labels, n_global, W, device=dev if backend == "nccl" else None)
+            labels = hdist.gather_labels(labels, n_global, W, device=dev if backend == "nccl" else None)
+            t_gather[0] += time.perf_counter() - t1
         return labels
 
-    for _ in range(args.warmup):
-        out = step()
-    model.set_profiling(True)
-    prof = {}
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-        for name, ms in model.last_profile():
-            prof.setdefault(name, []).append(ms)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    model.set_profiling(False)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(m, with_profile):
+        for _ in range(args.warmup):
+            out = step(m)
+        prof = {}
+        if with_profile:
+            m.set_profiling(True)
+        t_fwd[0] = t_gather[0] = 0.0
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(m)
+            if with_profile:
+                for name, ms in m.last_profile():
+                    prof.setdefault(name, []).append(ms)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        if with_profile:
+            m.set_profiling(False)
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return out, dt, prof
+
+    out, dt, prof = timed(model, True)
+    fwd_ms, gather_ms = t_fwd[0] / args.steps * 1e3, t_gather[0] / args.steps * 1e3
+    per_rank = None
+    if dist is not None:                                      # every rank's own forward time, for the record
+        t = torch.tensor([fwd_ms, gather_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [[round(float(v), 3) for v in x.cpu().tolist()] for x in allt]
 
     if rank != 0:
         if dist is not None:
@@ -129,82 +208,150 @@ def main():
         return
 
     lines_per_s = n_global * args.steps / dt
-    cols = B * W
-    dom_ms = [np.mean(prof[n]) for n in DOMINANT if n in prof]
+    # the dominant kernel's launch covers one internal pass of the engine (<= HCTR_MAX_COLS pixel columns)
+    pass_lines = B
+    if B * W > 131072:
+        nb = max(1, 131072 // W)
+        passes = -(-B // nb)
+        pass_lines = -(-B // passes)
+    n_pass = -(-B // pass_lines)
+    cols = pass_lines * W                                     # columns per dominant launch (last pass may be shorter)
+    dom_ms = [np.mean(prof[n]) / n_pass for n in DOMINANT if n in prof]
     dom_avg_ms = float(np.mean(dom_ms)) if dom_ms else float("nan")
-    dom_tflops = FLOP_PER_COL_DOM * cols / (dom_avg_ms * 1e-3) / 1e12
+    x3 = args.precision == "f16x3"
+    flop_per_launch = FLOP_PER_COL_DOM * (B * W / n_pass)
+    dom_tflops = flop_per_launch / (dom_avg_ms * 1e-3) / 1e12
     kernel_ms = float(sum(np.mean(v) for v in prof.values()))
-    # HBM-side traffic of the dominant kernel per launch: rocprofv3 PMC passes of this same command
-    # (tools/profile_rocprof.sh: FETCH_SIZE and WRITE_SIZE in separate runs, KiB units, FETCH_SIZE x2 on
-    # gfx950 as MI355X_MICROARCH.md prescribes), summarised into profiles/per_layer_latest.json.
-    traffic, traffic_src = None, None
+    # HBM-side traffic and matrix-pipe counters of the dominant kernel per launch: rocprofv3 PMC passes of this same
+    # command (tools/profile_rocprof.sh: FETCH_SIZE, WRITE_SIZE and the SQ set in separate runs, KiB units, FETCH_SIZE x2
+    # on gfx950 as MI355X_MICROARCH.md prescribes), summarised into profiles/per_layer_latest.json - NOT measured in
+    # this run (a PMC pass cannot share a process with the timed region).
+    traffic = traffic_src = busy = clock = None
     pj = os.path.join(ROOT, "profiles", "per_layer_latest.json")
-    if os.path.isfile(pj) and B == B_PER_GPU and W == W_LINE and args.precision == "f16":   # (PMC passes ran in f16)
+    if os.path.isfile(pj) and world == 1 and B == B_PER_GPU and W == W_LINE and not x3:   # (PMC passes ran in f16)
         with open(pj) as f:
             rows = [r for r in json.load(f) if r["layer"] in DOMINANT and r.get("fetch_gb_x2") is not None]
         if rows:
             traffic = float(np.mean([(r["fetch_gb_x2"] + r["write_gb"]) * 1e9 for r in rows]))
-            traffic_src = "profiles/per_layer_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            traffic_src = "profiles/per_layer_latest.json (rocprofv3 --pmc, separate passes of this command; not this run)"
+            b_ = [r["mfma_busy_pct"] for r in rows if r.get("mfma_busy_pct") is not None]
+            c_ = [r["clock_ghz"] for r in rows if r.get("clock_ghz") is not None]
+            busy = round(float(np.mean(b_)), 1) if b_ else None
+            clock = round(float(np.mean(c_)), 3) if c_ else None
     if args.layers:
         for name, v in prof.items():
             print("%-24s %9.3f ms" % (name, float(np.mean(v))), file=sys.stderr)
     if args.layer_file:
         with open(args.layer_file, "w") as f:
             f.write("\n".join(prof.keys()) + "\n")
+    dtype_name = {"f16": "f16 (f32 accumulate)", "f16x3": "f16x3 (hi+lo fp16 pairs, f32 accumulate)"}
     result = {
         "metric": "text-lines/sec (1x128x2000 synth) greedy decode",
         "value": round(lines_per_s, 3), "unit": "lines/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 (f32 accumulate)" if args.precision == "f16" else "f16x3 (hi+lo fp16 pairs, f32 accumulate)",
-        "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: B=%d x 1x128x%d uint8 lines per GPU, random-init hctr "
-                               "(C=%d), forward + greedy CTC decode, labels to host" % (B, W, C),
-                   "lines_per_gpu": B, "width": W, "classes": C, "parallelism": "batch-shard x%d" % world},
-        "roofline": {"bound": "mfma", "kernel": "conv3x3_halo4 3x3 512->512 @H=16 (%d plain launches/step averaged)" % len(dom_ms),
+        "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
+        "dtype": dtype_name[args.precision], "data": "synthetic",
+        "config": {"workload": "%s: %d x 1x128x%d uint8 lines%s, %s hctr checkpoint (C=%d), forward + greedy CTC "
+                               "decode, labels to host%s" %
+                               (cfg_name, n_global, W, "" if world == 1 else " in contiguous shards of %d" % B,
+                                "random-init" if args.checkpoint == "random" else "trained-like synthetic", C,
+                                "" if world == 1 else ", one gather to rank 0"),
+                   "global_lines": n_global, "lines_per_gpu": B, "width": W, "classes": C,
+                   "checkpoint": args.checkpoint, "parallelism": "batch-shard x%d" % world},
+        "roofline": {"bound": "mfma", "kernel": "conv3x3_halo4 3x3 512->512 @H=16 (%d launches per pass averaged)" % len(dom_ms),
                      "achieved": round(dom_tflops, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(dom_tflops / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                      "traffic_unit": "bytes/launch (algorithmic: 2.36e9 in + 2.36e9 out + 4.7e6 weights)",
-                     "traffic_source": traffic_src,
-                     "avg_launch_ms": round(dom_avg_ms, 4),
-                     "flops_per_launch": FLOP_PER_COL_DOM * cols},
+                     "traffic_source": traffic_src, "mfma_busy_pct": busy, "clock_ghz": clock,
+                     "avg_launch_ms": round(dom_avg_ms, 4), "flops_per_launch": flop_per_launch,
+                     "note": "algorithmic FLOPs (2*Cin*Cout*9 per output pixel); in f16x3 the kernel issues 3x that "
+                             "in MFMA work" if x3 else None},
         "whole_forward": {"kernel_ms_per_step": round(kernel_ms, 3),
-                          "tflops": round(FLOP_PER_COL_ALL * cols / (kernel_ms * 1e-3) / 1e12, 2)},
+                          "tflops": round(FLOP_PER_COL_ALL * B * W / (kernel_ms * 1e-3) / 1e12, 2)},
     }
+    if world > 1:
+        result["multi_gpu"] = {"world_size_reported_by_backend": dist.get_world_size(), "backend": backend,
+                               "per_rank_ms": {"columns": ["greedy (forward+decode+D2H)", "gather"], "rows": per_rank},
+                               "gather_bytes_per_rank": int(-(-n_global // world) * (1 + W) * 4)}
 
+    if world == 1:
+        codec = hctr_amd.ctc_codec(synth.characters())
+        meta = gold = None
+        if args.checkpoint == "random" and n_global == B_PER_GPU and W == W_LINE:
+            meta, gold = load_c2_golden()
+        elif args.checkpoint == "trained" and n_global == B_PER_GPU and W == W_LINE:
+            meta, gold = load_c2_golden_trained()
+        texts = {args.precision: codec.labels_to_text(out)}
+        if not args.no_second_mode:
+            # the other precision mode, timed by the same loop in the same process (K steps after W warm-ups)
+            other = "f16x3" if args.precision == "f16" else "f16"
+            del model
+            m2 = hctr_amd.hctr_model(C, precision=other).cuda(local)
+            m2.load_state_dict(sd)
+            out2, dt2, _ = timed(m2, False)
+            texts[other] = codec.labels_to_text(out2)
+            result["value_" + other] = round(n_global * args.steps / dt2, 3)
+            result["ms_per_step_" + other] = round(dt2 / args.steps * 1e3, 3)
+            result["dtype_" + other] = dtype_name[other]
+            del m2
+        if meta is not None:
+            for mode, tx in texts.items():
+                result["parity_vs_cpu" + ("" if mode == args.precision else "_" + mode)] = \
+                    dict(text_parity(tx, meta, n_global), mode=mode)
+            result["parity_note"] = PARITY_NOTE[args.checkpoint]
     if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 of the 1-GPU run only
+        # the CPU restatement (bit-equal to the reference here) on B=4 lines of the same
+        # workload, 1 warm-up + 3 timed passes, all host cores of the box
         from oracle import ctc_ref, hctr_ref
-        nl = max(1, args.cpu_lines)
+        nl = max(1, min(args.cpu_lines, B))
         x = synth.normalize_pad(imgs_host[:nl])
-        codec = ctc_ref.CtcCodecRef(synth.characters())
-        hctr_ref.forward(sd, x[:1, :, :, :64])                       # warm-up
-        t0 = time.perf_counter()
-        ref = hctr_ref.forward(sd, x).numpy()
-        ref_txt = codec.decode(ref)
-        cdt = time.perf_counter() - t0
-        got_txt = [codec.characters and "".join(codec.characters[i] for i in lab) for lab in out[:nl]]
-        ed = sum(ctc_ref.edit_distance(a, b) for a, b in zip(got_txt, ref_txt))
+        ocodec = ctc_ref.CtcCodecRef(synth.characters())
+        times = []
+        for it in range(4):
+            t0 = time.perf_counter()
+            ref_txt = ocodec.decode(hctr_ref.forward(sd, x).numpy())
+            if it:
+                times.append(time.perf_counter() - t0)
+        cdt = float(np.median(times))
         result["cpu_baseline"] = {"value": round(nl / cdt, 4), "unit": "lines/s", "cores": torch.get_num_threads(),
-                                  "kind": "port", "sample": "%d line(s) of 1x128x%d, oracle forward + greedy "
-                                  "(torch CPU fp32)" % (nl, W)}
-        result["parity_vs_cpu"] = {"mode": args.precision, "lines": nl,
-                                   "exact_lines": int(sum(a == b for a, b in zip(got_txt, ref_txt))),
-                                   "char_edits": int(ed), "ref_chars": int(sum(len(s) for s in ref_txt)),
-                                   "note": "random-weight logits have many near-ties; f16 matches the reference's "
-                                           "own TF32-class GPU precision, f16x3 is the fp32-grade mode"}
-        if args.precision == "f16":          # the same lines through the split-precision mode (untimed)
-            mx = hctr_amd.hctr_model(C, precision="f16x3").cuda(local)
-            mx.load_state_dict(sd)
-            lx = mx(imgs_host[:nl])
-            x3_txt = ["".join(codec.characters[i] for i in lab) for lab in mx.greedy(imgs_host[:nl])]
-            result["parity_vs_cpu_f16x3"] = {
-                "lines": nl, "exact_lines": int(sum(a == b for a, b in zip(x3_txt, ref_txt))),
-                "char_edits": int(sum(ctc_ref.edit_distance(a, b) for a, b in zip(x3_txt, ref_txt))),
-                "max_logit_err": float(np.abs(lx - ref).max()), "logit_scale": float(np.abs(ref).max())}
-            del mx
+                                  "cpu": cpu_model_name(), "kind": "port",
+                                  "sample": "%d line(s) of 1x128x%d, oracle forward + greedy (torch CPU fp32), 1 warm-up + "
+                                            "3 timed passes, median" % (nl, W),
+                                  "oracle_equals_golden_reference_text":
+                                      (ref_txt == meta["greedy"][:nl]) if world == 1 and meta is not None else None}
     print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+PARITY_NOTE = {
+    "random": "random-head checkpoint: 69 of the 128000 reference columns have a top-2 margin below 1e-3 (scale 41.5), 8 "
+              "below 1e-4 - closer than two fp32 summation orders agree; f16x3 is fp32-grade (|dlogit| ~5e-4), f16 has "
+              "the 10-bit mantissa of the TF32 mode the reference enables on GPUs. See --checkpoint trained for a "
+              "checkpoint with trained-like margins.",
+    "trained": "trained-like checkpoint: head fitted on trunk features so the logits are peaky like a trained CTC model's; "
+               "margin histogram in tests/golden/c2_trained_lines.json",
+}
+
+
+def make_checkpoint(synth, C, kind):
+    if kind == "trained":
+        return synth.make_state_dict(C, seed=0, head="trained")
+    return synth.make_state_dict(C, seed=0)
+
+
+def make_lines(synth, kind, n, W, seed, offset):
+    if kind == "trained":
+        return synth.make_font_lines(n, W, seed, line_offset=offset)
+    return synth.make_line_images(n, W, seed, line_offset=offset)
+
+
+def load_c2_golden_trained():
+    gdir = os.path.join(ROOT, "tests", "golden")
+    with open(os.path.join(gdir, "c2_trained_lines.json")) as f:
+        meta = json.load(f)
+    z = np.load(os.path.join(gdir, "c2_trained_lines.npz"))
+    return meta, {k: z[k] for k in z.files}
 
 
 def extra_config(args, hctr_amd, model, sd, dev):

@@ -60,3 +60,21 @@ def gather_labels(label_lists, n_lines, cap, device=None, group=None):
         lo, hi = shard_range(n_lines, r, world)
         result.extend(unpack_labels(outs[r].cpu().numpy()[:hi - lo]))
     return result
+
+
+def recognize_sharded(model, images, widths=None, device=None, group=None):
+    """Greedy-decode a batch that every rank can index, each rank taking its contiguous ``shard_range``.
+
+    ``images`` is the GLOBALLY padded uint8 batch [n,128,maxW] (plus each line's valid width): a line's SE means see
+    its pad columns (models/handwritten_ctr_model.py:27 over NormalizePAD's replicate pad, utils/dataset.py:83-93), so
+    the padded width must be fixed BEFORE sharding for N ranks to reproduce the one-rank result bit for bit
+    (SURVEY.md 8e). Returns the n label arrays in input order on rank 0, None elsewhere."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n, max_w = int(images.shape[0]), int(images.shape[2])
+    lo, hi = shard_range(n, rank, world)
+    if hi > lo:
+        mine = model.greedy(images[lo:hi], widths=None if widths is None else widths[lo:hi])
+    else:
+        mine = []
+    return gather_labels(mine, n, max_w, device=device, group=group)

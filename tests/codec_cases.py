@@ -93,3 +93,37 @@ def write_toy_arpa(path, n_chars=14, seed=7):
             f.write("%.6f\t%s %s %s\n" % (p, a, b, c))
         f.write("\n\\end\\\n")
     return path
+
+
+class FakeTransformer(object):
+    """Deterministic stand-in for the reference's transformer LM object (utils/transformer_infer.py:41-76 as used at
+    utils/ctc_codec.py:215-227,269-274): ``score(list[str], char_based=True) -> list[float]`` and
+    ``next_k_words(list[str], k=, char_based=True) -> list[list[str]]``. ``ragged`` makes next_k_words return FEWER
+    than k words for some prefixes (the reference chains whatever comes back)."""
+
+    def __init__(self, chars, ragged=False):
+        self.chars = list(chars)
+        self.ragged = ragged
+
+    def score(self, sentences, char_based=True):
+        from oracle import ctc_ref
+        return [ctc_ref.toy_bigram_score([ord(ch) for ch in s]) * 0.5 for s in sentences]
+
+    def next_k_words(self, prefixes, k=10, char_based=True):
+        out = []
+        for p in prefixes:
+            base = (ord(p[-1]) if p else 0) + len(p)
+            n = k if not self.ragged else max(0, k - (base % 4))
+            out.append([self.chars[(base + 3 * j) % len(self.chars)] for j in range(n)])
+        return out
+
+
+# transformer-hook cases: (name, seed, W, B, C, style, use_tfm_score, use_tfm_pred, ragged)
+TFM_CASES = [
+    ("score_only", 9, 36, 2, 16, "mixed", True, False, False),
+    ("pred_only", 9, 36, 2, 16, "mixed", False, True, False),
+    ("score_and_pred", 9, 36, 2, 16, "mixed", True, True, False),
+    ("pred_ragged", 11, 40, 2, 24, "flat", False, True, True),
+    ("both_ragged_peaky", 12, 48, 3, 40, "peaky", True, True, True),
+]
+TFM_SETTINGS = dict(search_depth=6, beam_size=5, lm_panelty=0.8, len_bonus=4.8)

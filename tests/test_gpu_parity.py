@@ -6,10 +6,12 @@ Two floating-point checks, both with the tolerance written here:
      stores activations/weights in fp16 and accumulates in fp32 (the reference's own GPU mode is
      TF32, the same 10-bit mantissa), so:
        logits  |err| <= LOGIT_RTOL * max|logit| + LOGIT_ATOL
-       argmax  bit-exact on every column whose reference top-2 margin exceeds 2x the measured max
-               error (a flip needs err(top1) + err(top2) > margin), and >= MIN_AGREE overall
-       text    edit distance to the reference string bounded by the number of ambiguous columns;
-               exact when a line has none
+       argmax  bit-exact on every column whose reference top-2 margin exceeds 2x that FIXED tolerance
+               (a flip needs err(top1) + err(top2) > margin); the share of such columns is a property of
+               the fixture and recorded per fixture (MIN_SAFE); >= MIN_AGREE of all columns agree
+       text    character error rate vs the reference string <= F16_CER_MAX (fixed; measured 2.4 % on the
+               64 config-2 lines, whose random-head logits have a near-tie in 1 column of 8); f16x3 mode and
+               the trained-like checkpoint carry the exact-text assertions
  (2) against the oracle with the engine's rounding points inserted (oracle.hctr_ref.forward_f16):
      end to end |err| <= 0.008 * max|logit| (rounding-boundary flips still decorrelate two fp16
      pipelines), but PER LAYER, from the engine's own activations, every element within one fp16
@@ -30,7 +32,31 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_RTOL = 0.01
 LOGIT_ATOL = 0.05
-MIN_AGREE = 0.95
+MIN_AGREE = 0.97        # measured 0.988 on the 128 000 columns of config 2 (gpurun r2a)
+F16_CER_MAX = 0.04      # measured 0.024 there
+# share of columns whose reference top-2 margin exceeds 2 * (LOGIT_RTOL * scale + LOGIT_ATOL): computed from the
+# fixtures alone (tests/golden), recorded here so that the coverage of the argmax-exact assertion is explicit
+MIN_SAFE = {"b1w32": 0.65, "b3w67u": 0.83, "b2w96": 0.82, "w488": 0.75, "w2000": 0.71, "b2w300u": 0.74,
+            "b4w131u": 0.85, "c1": 0.83, "c2": 0.66}
+
+
+def f16_tol(scale):
+    return LOGIT_RTOL * float(scale) + LOGIT_ATOL
+
+
+def check_f16_argmax(got_arg, ref_arg, margin, scale, min_safe):
+    """argmax identical on every column the FIXED tolerance cannot flip; overall agreement floor."""
+    safe = margin > 2 * f16_tol(scale)
+    assert safe.mean() >= min_safe, safe.mean()
+    assert np.array_equal(got_arg[safe], ref_arg[safe])
+    assert (got_arg == ref_arg).mean() >= MIN_AGREE
+    return safe
+
+
+def check_f16_text(mine, want):
+    """fixed character-error-rate bound (at least one edit is allowed on very short strings)"""
+    bound = max(1, int(np.ceil(F16_CER_MAX * len(want))))
+    assert ctc_ref.edit_distance(mine, want) <= bound, (ctc_ref.edit_distance(mine, want), bound, len(want))
 
 
 @pytest.fixture(scope="module")
@@ -64,10 +90,8 @@ def test_forward_matches_reference_fixture(engine, synth, name, seed, widths):
     err = float(np.abs(got[:, :, sub] - ref_sub).max())
     assert err <= tol, "max logit error %.4f > %.4f" % (err, tol)
     margin = g[name + "/top10_val"][:, :, 0] - g[name + "/top10_val"][:, :, 1]
-    safe = margin > 2 * err
-    ref_arg = g[name + "/argmax"].astype(np.int64)
-    assert np.array_equal(got.argmax(axis=2)[safe], ref_arg[safe])
-    assert (got.argmax(axis=2) == ref_arg).mean() >= MIN_AGREE
+    check_f16_argmax(got.argmax(axis=2), g[name + "/argmax"].astype(np.int64), margin, np.abs(ref_sub).max(),
+                     MIN_SAFE[name])
     # activations along the trunk (debug taps) against the reference's
     # block1.0 = first block of stage 1: fused SE + the 1x1 downsample branch inside conv2's K loop (buffer p1.1);
     # block3.4 = last block of stage 3 (buffer p3.0)   [buffer rotation: engine.cpp run_forward]
@@ -170,18 +194,10 @@ def test_long_line_against_reference_fixture(engine, codec, synth, name, seed, w
     tol = LOGIT_RTOL * float(np.abs(g[name + "/max"]).max()) + LOGIT_ATOL
     assert err <= tol
     margin = g[name + "/top10_val"][:, :, 0] - g[name + "/top10_val"][:, :, 1]
-    safe = margin > 2 * max(err, 1e-3)
-    amax = got.argmax(axis=2)
-    ref_arg = g[name + "/argmax"].astype(np.int64)
-    assert np.array_equal(amax[safe], ref_arg[safe])
-    assert (amax == ref_arg).mean() >= MIN_AGREE
-    ambiguous = int((~safe).sum())
+    check_f16_argmax(got.argmax(axis=2), g[name + "/argmax"].astype(np.int64), margin, np.abs(g[name + "/max"]).max(),
+                     MIN_SAFE[name])
     text = codec.labels_to_text(engine.greedy(imgs))[0]
-    ref_text = strings[name]["greedy"][0]
-    dist = ctc_ref.edit_distance(text, ref_text)
-    assert dist <= 2 * ambiguous, (dist, ambiguous)
-    if ambiguous == 0:
-        assert text == ref_text
+    check_f16_text(text, strings[name]["greedy"][0])
 
 
 def test_config1_bundled_images(engine, codec):
@@ -194,13 +210,10 @@ def test_config1_bundled_images(engine, codec):
         got = engine(img[None])
         err = float(np.abs(got.max(axis=2) - g[key + "/max"]).max())
         assert err <= LOGIT_RTOL * float(np.abs(g[key + "/max"]).max()) + LOGIT_ATOL, key
-        safe = g[key + "/top2_margin"] > 2 * max(err, 1e-3)
-        ref_arg = g[key + "/argmax"].astype(np.int64)
-        assert np.array_equal(got.argmax(axis=2)[safe], ref_arg[safe]), key
-        assert (got.argmax(axis=2) == ref_arg).mean() >= MIN_AGREE, key
+        check_f16_argmax(got.argmax(axis=2), g[key + "/argmax"].astype(np.int64), g[key + "/top2_margin"],
+                         np.abs(g[key + "/max"]).max(), MIN_SAFE["c1"])
         text = codec.labels_to_text(engine.greedy(img[None]))[0]
-        dist = ctc_ref.edit_distance(text, strings["c1_" + key]["greedy"][0])
-        assert dist <= 2 * int((~safe).sum()), key
+        check_f16_text(text, strings["c1_" + key]["greedy"][0])
 
 
 def test_codec_cases_on_device(pkg):
@@ -479,8 +492,8 @@ def test_f16x3_mode_matches_reference_closely(engine_x3, pkg, synth, name, seed,
 
 
 def test_f16x3_long_line_text(engine_x3, pkg, synth):
-    """W = 2000 (config-2 width): in f16x3 mode the greedy text is within a few edits of the fp32 CPU
-    reference's (tests/golden/model_strings.json), vs ~2.5 % CER in the default f16 mode."""
+    """W = 2000 (config-2 width): in f16x3 mode the greedy text EQUALS the fp32 CPU reference's
+    (tests/golden/model_strings.json), vs ~2.4 % CER in the default f16 mode."""
     g = np.load(os.path.join(GOLDEN, "model_lines.npz"))
     with open(os.path.join(GOLDEN, "model_strings.json")) as f:
         strings = json.load(f)
@@ -492,7 +505,7 @@ def test_f16x3_long_line_text(engine_x3, pkg, synth):
     assert agree >= 0.999
     cd = pkg.ctc_codec(synth.characters()).attach(engine_x3)
     text = cd.labels_to_text(engine_x3.greedy(imgs))[0]
-    assert ctc_ref.edit_distance(text, strings["w2000"]["greedy"][0]) <= 3
+    assert text == strings["w2000"]["greedy"][0]          # exact (this line has no column with a margin below 2e-4)
 
 
 def test_model_moves_and_attached_codec(pkg, synth, state_dict):
@@ -646,20 +659,15 @@ def test_forward_matches_reference_extra_fixtures(engine, codec, synth, name, se
     err = float(np.abs(got[:, :, g["sub_classes"]] - ref_sub).max())
     assert err <= tol, "max logit error %.4f > %.4f" % (err, tol)
     margin = g[name + "/top10_val"][:, :, 0] - g[name + "/top10_val"][:, :, 1]
-    safe = margin > 2 * err
-    ref_arg = g[name + "/argmax"].astype(np.int64)
-    assert np.array_equal(got.argmax(axis=2)[safe], ref_arg[safe])
-    assert (got.argmax(axis=2) == ref_arg).mean() >= MIN_AGREE
+    check_f16_argmax(got.argmax(axis=2), g[name + "/argmax"].astype(np.int64), margin, np.abs(ref_sub).max(),
+                     MIN_SAFE[name])
     for tap, buf in (("stage1", "stage1"), ("stage3", "stage3"), ("block1.0", "p1.1"), ("block3.4", "p3.0")):
         a = engine.debug_activation(buf, len(widths))[:, :8, :, :16]
         r = g[name + "/act/" + tap]
         assert np.abs(a - r).max() <= 0.02 * np.abs(r).max() + 0.02, tap
     text = codec.labels_to_text(engine.greedy(imgs, widths=widths))
-    for b, (mine, want) in enumerate(zip(text, strings["greedy"])):
-        amb = int((~safe[:, b]).sum())
-        assert ctc_ref.edit_distance(mine, want) <= 2 * amb, (b, amb)
-        if amb == 0:
-            assert mine == want
+    for mine, want in zip(text, strings["greedy"]):
+        check_f16_text(mine, want)
 
 
 def test_plain_c_caller_matches_python(tmp_path, engine, synth):
@@ -739,3 +747,83 @@ def test_kernel_families_agree_over_random_shapes(tmp_path):
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     r = subprocess.run([sys.executable, tool, "compare", a, b], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_two_ranks_equal_one_rank():
+    """the same 6-line unequal-width batch decoded by 1 rank and by 2 ranks (contiguous shards,
+    global pad width fixed before sharding, ONE gather) gives identical label arrays in identical order. Two
+    processes share this box's GPU; the gather runs over gloo (RCCL needs one GPU per rank)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517",
+                        os.path.join(ROOT, "tests", "dist_identity_worker.py")], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "IDENTITY_OK world=2 lines=6" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_bench_strong_scaling_rehearsal():
+    """bench.py --gpus 2: BASELINE configs[3]'s flow (fixed global batch cut into contiguous shards, one gather per
+    step, strong scaling) rehearsed with two ranks on this box's one GPU over gloo at a reduced batch."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HCTR_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29518", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "10", "--width", "320"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["config"]["global_lines"] == 10
+    assert res["config"]["lines_per_gpu"] == 5 and res["multi_gpu"]["world_size_reported_by_backend"] == 2
+    assert res["value"] > 0 and len(res["multi_gpu"]["per_rank_ms"]["rows"]) == 2
+
+
+def _c2_columns(model, imgs, chunk=8):
+    """per-column argmax [n, W] of the engine's logits (read back in chunks of 8 lines = 0.47 GB)"""
+    out = np.zeros((imgs.shape[0], imgs.shape[2]), np.int64)
+    for s0 in range(0, imgs.shape[0], chunk):
+        out[s0:s0 + chunk] = model(imgs[s0:s0 + chunk]).argmax(axis=2).T
+    return out
+
+
+def test_config2_all_64_lines_against_the_real_reference(engine, engine_x3, codec, synth):
+    """BASELINE configs[1] at full size against the REAL reference's outputs for all 64 lines (tests/golden/c2_lines.*,
+    made by make_golden_c2.py): per-column argmax and greedy text, both precision modes, FIXED floors (recorded from
+    gpurun r2a: f16 1507 flips / 128 000 columns, none above a reference margin of 0.21, 2.4 % CER; f16x3 4 flips, all
+    below a margin of 7.1e-5 - fp32-rounding territory - 60 of 64 lines exact, 4 character edits)."""
+    with open(os.path.join(GOLDEN, "c2_lines.json"), encoding="utf-8") as f:
+        meta = json.load(f)
+    g = np.load(os.path.join(GOLDEN, "c2_lines.npz"))
+    ref_arg, margin = g["argmax"].astype(np.int64), g["margin"]
+    scale = float(np.abs(g["max"]).max())
+    imgs = synth.make_line_images(64, 2000, meta["seed"])
+    ref_text = meta["greedy"]
+
+    # ---- f16 (the timed default): tolerance-qualified ------------------------------------------------
+    arg = _c2_columns(engine, imgs)
+    check_f16_argmax(arg, ref_arg, margin, scale, MIN_SAFE["c2"])
+    flips = arg != ref_arg
+    assert not flips[margin > 0.3].any()                      # tighter recorded fact: measured largest 0.21
+    assert flips.sum() <= 2000
+    text = codec.labels_to_text(engine.greedy(imgs))
+    edits = sum(ctc_ref.edit_distance(a, b) for a, b in zip(text, ref_text))
+    assert edits <= F16_CER_MAX * sum(len(t) for t in ref_text), edits
+
+    # ---- f16x3: fp32-grade ------------------------------------------------------------------------------
+    arg3 = _c2_columns(engine_x3, imgs)
+    flips3 = arg3 != ref_arg
+    assert not flips3[margin > 2e-4].any()                    # (2e-4 = 4.8e-6 of the logit scale)
+    assert flips3.sum() <= 12
+    assert (arg3 == g["second"].astype(np.int64))[flips3].all()          # a flip only ever swaps the reference's top two
+    text3 = codec.labels_to_text(engine_x3.greedy(imgs))
+    assert sum(a == b for a, b in zip(text3, ref_text)) >= 58
+    assert sum(ctc_ref.edit_distance(a, b) for a, b in zip(text3, ref_text)) <= 8
+    for b in range(64):                                       # every line without a sub-2e-4 near-tie is EXACT
+        if (margin[b] > 2e-4).all():
+            assert text3[b] == ref_text[b], b

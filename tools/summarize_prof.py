@@ -93,17 +93,36 @@ def per_layer(d):
             rows = [r for r in csv.DictReader(open(files[0])) if "hctr" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
             rows.sort(key=lambda r: int(r["Dispatch_Id"]))
             pm[kind] = rows[-n:] if len(rows) >= n else None
+    # matrix-pipe pass: busy = SQ_VALU_MFMA_BUSY_CYCLES / (128 * GRBM_GUI_ACTIVE), clock = GRBM_GUI_ACTIVE / 8 / time
+    mfma = {}
+    files = glob.glob(os.path.join(d, "pmc_mfma", "*", "*_counter_collection.csv"))
+    if files:
+        allrows = [r for r in csv.DictReader(open(files[0])) if "hctr" in r["Kernel_Name"]]
+        for ctr in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
+            rows = [r for r in allrows if r["Counter_Name"] == ctr]
+            rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+            mfma[ctr] = rows[-n:] if len(rows) >= n else None
     print("\n## Last step, per launch\n")
-    print("| layer | kernel | ms | FETCH_SIZE GB (raw / x2) | WRITE_SIZE GB |")
-    print("|---|---|---|---|---|")
+    print("| layer | kernel | ms | FETCH_SIZE GB (raw / x2) | WRITE_SIZE GB | MFMA pipe busy % | clock GHz |")
+    print("|---|---|---|---|---|---|---|")
     out = []
     for i, (nm, r) in enumerate(zip(names, last)):
         ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
         f = float(pm["fetch"][i]["Counter_Value"]) * 1024 / 1e9 if pm.get("fetch") else None
         w = float(pm["write"][i]["Counter_Value"]) * 1024 / 1e9 if pm.get("write") else None
-        print("| %s | %s | %.3f | %s | %s |" % (nm, short(r["Kernel_Name"]), ms,
-              "%.3f / %.3f" % (f, 2 * f) if f is not None else "-", "%.3f" % w if w is not None else "-"))
-        out.append({"layer": nm, "ms": ms, "fetch_gb_x2": 2 * f if f is not None else None, "write_gb": w})
+        busy = clk = None
+        if mfma.get("GRBM_GUI_ACTIVE") and mfma.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            g = mfma["GRBM_GUI_ACTIVE"][i]
+            gui = float(g["Counter_Value"])
+            tns = int(g["End_Timestamp"]) - int(g["Start_Timestamp"])
+            if gui > 0 and tns > 0:
+                busy = 100.0 * float(mfma["SQ_VALU_MFMA_BUSY_CYCLES"][i]["Counter_Value"]) / (128.0 * gui)
+                clk = gui / 8.0 / tns
+        print("| %s | %s | %.3f | %s | %s | %s | %s |" % (nm, short(r["Kernel_Name"]), ms,
+              "%.3f / %.3f" % (f, 2 * f) if f is not None else "-", "%.3f" % w if w is not None else "-",
+              "%.1f" % busy if busy is not None else "-", "%.3f" % clk if clk is not None else "-"))
+        out.append({"layer": nm, "ms": ms, "fetch_gb_x2": 2 * f if f is not None else None, "write_gb": w,
+                    "mfma_busy_pct": busy, "clock_ghz": clk})
     import json
     with open(os.path.join(d, "per_layer.json"), "w") as fjs:
         json.dump(out, fjs, indent=1)
