@@ -71,6 +71,14 @@ struct Workspace {
     int32_t* amax_idx = nullptr;
     int32_t* labels = nullptr;      // [B][W]
     int32_t* lengths = nullptr;     // [B]
+    // fused beam front end (allocated on first use, ensure_beam_ws): see ConvArgs in kernels.h
+    float* psum = nullptr;          // [P][B*W]
+    float* blank_logit = nullptr;   // [B*W]
+    float* row_thr = nullptr;       // [B*W][2]
+    int32_t* emit_cnt = nullptr;    // [B*W]
+    int32_t* emit_list = nullptr;   // [B*W][kBeamCap][2]
+    double* esum = nullptr;         // [P][B*W]
+    int32_t* overflow = nullptr;    // [1]
     std::vector<void*> allocs;
     size_t bytes = 0;
 };
@@ -115,6 +123,8 @@ struct hctr_ctx {
     int64_t stamp_cap = 0, stamp_n = 0;
     bool fuse_ds = true;             // 1x1 downsample inside conv2's K loop (HCTR_FUSE_DS=0: own launch + residual)
     bool fuse_argmax = true;         // greedy: argmax in the head GEMM's epilogue (HCTR_FUSE_ARGMAX=0: separate pass)
+    bool fuse_beam = true;           // beam front end without stored logits (HCTR_FUSE_BEAM=0: logits + row_topk)
+    int64_t beam_fallbacks = 0;      // passes that overflowed a row list and were redone through the logits
     // profiling
     bool profiling = false;
     std::vector<ProfEntry> prof;
@@ -457,6 +467,29 @@ int ensure_logits(hctr_ctx* c) {
     return HCTR_OK;
 }
 
+// scratch of the fused beam front end for the active workspace (first beam call on this shape)
+int ensure_beam_ws(hctr_ctx* c) {
+    if (c->ws.emit_list) return HCTR_OK;
+    if (c->ws_cache.empty() || c->ws_cache.front().B != c->ws.B || c->ws_cache.front().W != c->ws.W)
+        return fail(c, HCTR_ERR_STATE, "no active workspace");
+    Workspace& slot = c->ws_cache.front();
+    const size_t cols = (size_t)slot.B * slot.W, P = (size_t)c->cpad / 128;
+    int rc = HCTR_OK;
+    auto A = [&](auto** out, size_t count) {
+        if (rc == HCTR_OK) rc = dev_alloc(c, slot.allocs, out, count, false, &slot.bytes);
+    };
+    A(&slot.psum, P * cols);
+    A(&slot.blank_logit, cols);
+    A(&slot.row_thr, 2 * cols);
+    A(&slot.emit_cnt, cols);
+    A(&slot.esum, P * cols);
+    A(&slot.overflow, 1);
+    A(&slot.emit_list, cols * kBeamCap * 2);          // last: emit_list != NULL means the whole set exists
+    if (rc != HCTR_OK) slot.emit_list = nullptr;
+    c->ws = slot;
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward orchestration
 // ---------------------------------------------------------------------------------------------
@@ -617,8 +650,24 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
 // trunk + head for the staged batch in ws.img: leaves [B*W][cpad] fp32 logits in ws.logits, or - greedy
 // decode, fused_argmax - only the per-column argmax in ws.colidx (the 29 kB-per-column logits never exist).
 // ResNet.forward :115-153 and hctr_model.forward :171-176; np.argmax(preds, 2) utils/ctc_codec.py:75.
-int run_forward(hctr_ctx* c, int img_f32, bool have_widths, bool fused_argmax = false) {
-    if (!fused_argmax) TRY(ensure_logits(c));
+enum HeadMode { HEAD_LOGITS = 0, HEAD_ARGMAX = 1, HEAD_BEAM = 2 };
+
+// the head projection's launch arguments for the active workspace (models/handwritten_ctr_model.py:175)
+void head_args(hctr_ctx* c, ConvArgs* out, ConvTile* tile) {
+    const Workspace& ws = c->ws;
+    ConvArgs a{};
+    a.x = ws.headin; a.w = c->head.w; a.bias = c->head.bias; a.y = ws.logits;
+    a.Cin = c->head.cin; a.Cout = c->num_classes; a.CoutPad = c->cpad;
+    a.M = (int64_t)ws.B * ws.W; a.ldo = c->cpad;
+    *tile = (c->big_tiles && c->cpad % 256 == 0) ? TILE_256x256 : TILE_128x128;
+    const int hbm = *tile == TILE_256x256 ? 256 : 128;
+    a.mtiles = (int)((a.M + hbm - 1) / hbm); a.ntiles = c->cpad / hbm;
+    *out = a;
+}
+
+int run_forward(hctr_ctx* c, int img_f32, bool have_widths, HeadMode mode = HEAD_LOGITS) {
+    if (mode == HEAD_LOGITS) TRY(ensure_logits(c));
+    if (mode == HEAD_BEAM) TRY(ensure_beam_ws(c));
     Workspace& ws = c->ws;
     Prof pf(c);
     pf.begin("stem.conv0_1");
@@ -652,20 +701,18 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths, bool fused_argmax = 
         cin = planes;
     }
     // head GEMM
-    ConvArgs a{};
-    a.x = ws.headin; a.w = c->head.w; a.bias = c->head.bias; a.y = ws.logits;
-    a.Cin = c->head.cin; a.Cout = c->num_classes; a.CoutPad = c->cpad;
-    a.M = (int64_t)ws.B * ws.W; a.ldo = c->cpad;
-    const ConvTile htile = (c->big_tiles && c->cpad % 256 == 0) ? TILE_256x256 : TILE_128x128;
-    const int hbm = htile == TILE_256x256 ? 256 : 128;
-    a.mtiles = (int)((a.M + hbm - 1) / hbm); a.ntiles = c->cpad / hbm;
-    if (fused_argmax) {
+    ConvArgs a;
+    ConvTile htile;
+    head_args(c, &a, &htile);
+    if (mode == HEAD_ARGMAX || mode == HEAD_BEAM) {
         a.y = nullptr;
         a.amax_val = ws.amax_val;
         a.amax_idx = ws.amax_idx;
-        pf.begin("head.linear+argmax");
+        if (mode == HEAD_BEAM) { a.psum = ws.psum; a.blank_logit = ws.blank_logit; }
+        pf.begin(mode == HEAD_BEAM ? "head.linear+partials" : "head.linear+argmax");
         HIP_TRY(c, launch_conv(a, htile, 1, true, c->stream));
         pf.end();
+        if (mode == HEAD_BEAM) return HCTR_OK;
         pf.begin("argmax_partials");
         HIP_TRY(c, launch_argmax_partials(ws.amax_val, ws.amax_idx, a.ntiles * kLinearWN, a.M, ws.colidx, c->stream));
         pf.end();
@@ -673,6 +720,34 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths, bool fused_argmax = 
     }
     pf.begin("head.linear");
     HIP_TRY(c, launch_conv(a, htile, 1, true, c->stream));
+    pf.end();
+    return HCTR_OK;
+}
+
+// second half of the fused beam front end for the active workspace (after run_forward(HEAD_BEAM)): thresholds, the
+// head GEMM once more with the list-emitting epilogue, selection. Device outputs are indexed r = t*B + b.
+int beam_finish(hctr_ctx* c, int k, bool want_candidates, double thresh, int32_t* d_idx, float* d_lp, float* d_bl,
+                float* d_st, int32_t* d_cnt) {
+    Workspace& ws = c->ws;
+    Prof pf(c);
+    ConvArgs a;
+    ConvTile htile;
+    head_args(c, &a, &htile);
+    const int P = a.ntiles * kLinearWN;
+    pf.begin("beam_thresholds");
+    HIP_TRY(c, launch_beam_thresholds(ws.amax_val, ws.psum, P, a.M, k, thresh, want_candidates ? 1 : 0, ws.row_thr,
+                                      ws.emit_cnt, c->stream));
+    pf.end();
+    a.y = nullptr;
+    a.row_thr = ws.row_thr; a.emit_cnt = ws.emit_cnt; a.emit_list = ws.emit_list; a.emit_cap = kBeamCap;
+    a.esum = ws.esum;
+    pf.begin("head.linear+lists");
+    HIP_TRY(c, launch_conv(a, htile, 1, true, c->stream));
+    pf.end();
+    HIP_TRY(c, hipMemsetAsync(ws.overflow, 0, 4, c->stream));
+    pf.begin("beam_select");
+    HIP_TRY(c, launch_beam_select(ws.row_thr, ws.emit_cnt, ws.emit_list, kBeamCap, ws.esum, P, ws.blank_logit, ws.B, ws.W,
+                                  k, thresh, d_idx, d_lp, d_bl, d_st, d_cnt, ws.overflow, c->stream));
     pf.end();
     return HCTR_OK;
 }
@@ -758,6 +833,7 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
         if (const char* fs = getenv("HCTR_FUSE_SE")) c->fuse_se = atoi(fs) != 0;
         if (const char* fa = getenv("HCTR_FUSE_ARGMAX")) c->fuse_argmax = atoi(fa) != 0;
         if (const char* fd = getenv("HCTR_FUSE_DS")) c->fuse_ds = atoi(fd) != 0;
+        if (const char* fb = getenv("HCTR_FUSE_BEAM")) c->fuse_beam = atoi(fb) != 0;
         if (const char* wb = getenv("HCTR_WS_BUDGET_GB")) {
             const long long v = atoll(wb);
             if (v > 0) c->ws_budget = (size_t)v << 30;
@@ -949,7 +1025,7 @@ int hctr_greedy(hctr_ctx* c, const void* img, int img_dtype, int img_on_device, 
         auto pass = [&](int b0, int nb) -> int {
             TRY(ensure_workspace(c, nb, W));
             TRY(stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W));
-            TRY(run_forward(c, img_dtype == HCTR_F32, widths != nullptr, c->fuse_argmax));
+            TRY(run_forward(c, img_dtype == HCTR_F32, widths != nullptr, c->fuse_argmax ? HEAD_ARGMAX : HEAD_LOGITS));
             Workspace& ws = c->ws;
             Prof pf(c);
             if (!c->fuse_argmax) {
@@ -1050,10 +1126,14 @@ int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_d
             free_pool(pool);
             const float* rowsrc = nullptr;
             int64_t ld = 0;
+            // fused front end (default): the logits are never stored; the head GEMM runs twice with reducing epilogues
+            // (kernels.h ConvArgs). Not for k beyond the part count / kBeamMaxK, and a pass in which some row needed
+            // more than kBeamCap list slots (near-uniform logits) is redone through the stored-logits kernels.
+            bool fused = from_img && c->fuse_beam && k <= kBeamMaxK && k <= c->cpad / 128;
             if (from_img) {
                 rc = ensure_workspace(c, nb, W);
                 if (rc == HCTR_OK) rc = stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W);
-                if (rc == HCTR_OK) rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr);
+                if (rc == HCTR_OK) rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr, fused ? HEAD_BEAM : HEAD_LOGITS);
                 rowsrc = c->ws.logits; ld = c->cpad;
             } else {
                 float *up = nullptr, *rowsbuf = nullptr;
@@ -1081,7 +1161,30 @@ int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_d
             if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_st, (size_t)rows * 2, false);
             if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_cnt, (size_t)rows, false);
             if (rc != HCTR_OK) break;
-            hipError_t e = launch_row_topk(rowsrc, ld, nb, W, C, k, thresh, d_idx, d_lp, d_bl, d_st, d_cnt, c->stream);
+            hipError_t e = hipSuccess;
+            if (fused) {
+                rc = beam_finish(c, k, want_candidates != 0, thresh, d_idx, d_lp, d_bl, d_st, d_cnt);
+                int32_t ovf = 0;
+                if (rc == HCTR_OK) {
+                    e = hipMemcpyAsync(&ovf, c->ws.overflow, 4, hipMemcpyDeviceToHost, c->stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                    if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "beam overflow flag: %s", hipGetErrorString(e));
+                }
+                if (rc != HCTR_OK) break;
+                if (ovf) {                       // redo this pass with stored logits
+                    fused = false;
+                    ++c->beam_fallbacks;
+                    rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr, HEAD_LOGITS);
+                    if (rc != HCTR_OK) break;
+                    rowsrc = c->ws.logits;
+                }
+            }
+            if (!fused) {
+                Prof pf(c);
+                pf.begin("row_topk");
+                e = launch_row_topk(rowsrc, ld, nb, W, C, k, thresh, d_idx, d_lp, d_bl, d_st, d_cnt, c->stream);
+                pf.end();
+            }
             if (e != hipSuccess) { rc = fail(c, HCTR_ERR_HIP, "row_topk: %s (C=%d)", hipGetErrorString(e), C); break; }
             h_idx.resize((size_t)rows * k); h_lp.resize((size_t)rows * k); h_bl.resize(rows); h_cnt.resize(rows);
             e = hipMemcpyAsync(h_idx.data(), d_idx, (size_t)rows * k * 4, hipMemcpyDeviceToHost, c->stream);
@@ -1115,7 +1218,10 @@ int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_d
             if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_cl, (size_t)std::max<int64_t>(tot, 1), false);
             if (rc != HCTR_OK) break;
             e = hipMemcpyAsync(d_off, po.loff.data(), (size_t)(rows + 1) * 8, hipMemcpyHostToDevice, c->stream);
-            if (e == hipSuccess) e = launch_row_candidates(rowsrc, ld, nb, W, C, thresh, d_st, d_off, d_ci, d_cl, c->stream);
+            if (e == hipSuccess)
+                e = fused ? launch_beam_candidates(c->ws.emit_cnt, c->ws.emit_list, kBeamCap, d_st, nb, W, thresh, d_off, d_ci,
+                                                   d_cl, c->stream)
+                          : launch_row_candidates(rowsrc, ld, nb, W, C, thresh, d_st, d_off, d_ci, d_cl, c->stream);
             if (e == hipSuccess && tot) e = hipMemcpyAsync(po.ci.data(), d_ci, (size_t)tot * 4, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess && tot) e = hipMemcpyAsync(po.cl.data(), d_cl, (size_t)tot * 4, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

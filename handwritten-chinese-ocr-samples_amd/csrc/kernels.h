@@ -40,6 +40,20 @@ struct ConvArgs {
     // amax_val/amax_idx[(nt*WN + wn) * M + m]; launch_argmax_partials picks the first maximum per row.
     float* amax_val;
     int32_t* amax_idx;
+    // linear mode, fused beam front end (log_softmax + top-k + p > 0.001 lists, utils/ctc_codec.py:65,127-128,144,186)
+    // without storing the logits. PASS 1 = the argmax partials above plus, when psum is set, per (part, row) the sum of
+    // expf(v - part max) and the logit of class 0 per row. launch_beam_thresholds turns those into per-row
+    // {vmin, gmax}: every logit >= vmin is among the row's top-k or above the candidate threshold.
+    // PASS 2 (emit_cnt set; the same GEMM again, 2.5 % of a forward) appends every (class, logit >= vmin) to the
+    // row's list (atomic slot counter, emit_cap slots) and writes per (part, row) the float64 sum of
+    // expf(v - gmax) - the same terms the unfused row_topk kernel sums. launch_beam_select finishes the rows.
+    float* psum;
+    float* blank_logit;
+    const float* row_thr;     // [M][2] = {vmin, gmax}
+    int32_t* emit_cnt;        // [M], zeroed by launch_beam_thresholds
+    int32_t* emit_list;       // [M][emit_cap][2] = {class, float bits}
+    int emit_cap;
+    double* esum;             // [P][M]
     int split;              // f16x3 mode: activations are [hi | lo | hi] fp16 planes of Cout channels each
                             // (input side: Cin already counts the tripled channels)
     // fused 1x1 downsample of a block's input (first block of stages 1-3): the halo4 kernel first accumulates
@@ -95,6 +109,25 @@ hipError_t launch_se_apply(half_t* o, const half_t* r, const float* scale, int64
 // tB > 0: rows are in WBC order (r = t*tB + b) and idx is written as [b][t] with row length tW
 hipError_t launch_argmax_rows(const float* logits, int64_t ld, int64_t M, int C, int32_t* idx,
                               int tB, int tW, hipStream_t s);
+
+// ---- fused beam front end (see ConvArgs): P = ntiles * kLinearWN class parts per row, rows m = b*W + t ----
+constexpr int kBeamCap = 256;         // list slots per row; a row that needs more makes the engine fall back
+constexpr int kBeamMaxK = 32;         // largest top-k the fused path serves
+// after pass 1: row_thr[m] = {min(k-th largest part maximum, candidate value bound), row max}; emit_cnt[m] = 0.
+// cand_thresh: log-prob threshold of the candidate lists (ln 0.001) or +inf when they are not wanted.
+hipError_t launch_beam_thresholds(const float* pmax, const float* psum, int P, int64_t M, int k, double cand_thresh,
+                                  int want_candidates, float* row_thr, int32_t* emit_cnt, hipStream_t s);
+// after pass 2: exact float32 log-softmax terms of the listed classes (row max, float64 exp-sum as row_topk computes
+// them), top-k by (log-prob desc, class asc), log-prob of class 0, count of classes above cand_thresh; outputs are
+// indexed r = t*B + b like launch_row_topk's. overflow[0] is set to 1 if any row needed more than cap slots.
+hipError_t launch_beam_select(const float* row_thr, const int32_t* emit_cnt, const int32_t* emit_list, int cap,
+                              const double* esum, int P, const float* blank_logit, int B, int W, int k,
+                              double cand_thresh, int32_t* topk_idx, float* topk_logp, float* blank_logp,
+                              float* stats, int32_t* cand_count, int32_t* overflow, hipStream_t s);
+// candidate lists (ascending class order, log-prob > cand_thresh) out of the per-row lists, to cand_off[r] (r = t*B + b)
+hipError_t launch_beam_candidates(const int32_t* emit_cnt, const int32_t* emit_list, int cap, const float* stats,
+                                  int B, int W, double cand_thresh, const int64_t* cand_off, int32_t* cand_idx,
+                                  float* cand_logp, hipStream_t s);
 
 // raw per-column indices [B][W] (row m = b*W + t) -> collapsed labels [B][W] + lengths [B]
 hipError_t launch_ctc_collapse(const int32_t* idx, int B, int W, int C, int32_t* labels,

@@ -104,6 +104,42 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
     }
 
     estamp(8);
+    if (LINEAR && a.emit_cnt != nullptr) {
+        // fused beam front end, PASS 2 (see ConvArgs): list every (class, logit >= vmin[row]) and sum the row's
+        // float64 exp terms expf(v - gmax) per class part - the terms row_topk_kernel sums over a stored row.
+        static_assert(!LINEAR || WN == kLinearWN, "partials per n-tile");
+        const int64_t part = (int64_t)((n0 / BN) * WN + wn) * a.M;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int64_t m = (int64_t)mt * BM + wm * 64 + n * 16 + c;
+            const bool mv = m < a.M;
+            const float vmin = mv ? a.row_thr[2 * m] : INFINITY;
+            const float gmax = mv ? a.row_thr[2 * m + 1] : 0.f;
+            double es = 0.0;
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cls = cw0 + co(j) + i;
+                    const float v = acc[j][n][i];
+                    if (cls < a.Cout) {
+                        es += (double)expf(v - gmax);
+                        if (v >= vmin) {
+                            const int pos = atomicAdd(a.emit_cnt + m, 1);
+                            if (pos < a.emit_cap) {
+                                int32_t* e = a.emit_list + ((int64_t)m * a.emit_cap + pos) * 2;
+                                e[0] = cls;
+                                e[1] = __builtin_bit_cast(int32_t, v);
+                            }
+                        }
+                    }
+                }
+            es += __shfl_xor(es, 16);
+            es += __shfl_xor(es, 32);
+            if (q == 0 && mv) a.esum[part + m] = es;
+        }
+        return;
+    }
     if (LINEAR && a.amax_idx != nullptr) {
         // fused greedy argmax: classes rise with (j, i) for a lane and with q, wn, nt beyond it, so a strict
         // '>' keeps the first maximum inside a lane and the (value, class) merge keeps it across lanes.
@@ -131,6 +167,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
             if (q == 0 && m < a.M) {
                 a.amax_val[part + m] = bv;
                 a.amax_idx[part + m] = bi;
+            }
+            if (a.psum != nullptr) {
+                // beam front end, PASS 1: sum of expf(v - part max) per (part, row), and the logit of class 0
+                float ps = 0.f;
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (cw0 + co(j) + i < a.Cout) ps += expf(acc[j][n][i] - bv);
+                ps += __shfl_xor(ps, 16);
+                ps += __shfl_xor(ps, 32);
+                if (q == 0 && m < a.M) {
+                    a.psum[part + m] = ps;
+                    if (cw0 == 0) a.blank_logit[m] = acc[0][n][0];          // cw0 == 0: n0 == 0, wn == 0 (and q == 0)
+                }
             }
         }
         return;
@@ -1894,6 +1945,181 @@ hipError_t launch_row_candidates(const float* logits, int64_t ld, int B, int W, 
     if ((int64_t)B * W == 0) return hipSuccess;
     hipLaunchKernelGGL(row_candidates_kernel, dim3((unsigned)((int64_t)B * W)), dim3(64), 0, s, logits, ld, B, W, C,
                        thresh, stats, cand_off, cand_idx, cand_logp);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------
+// Fused beam front end (see ConvArgs in kernels.h): the two small kernels between / after the two head passes.
+// Same arithmetic as row_topk_kernel on a stored row: float32 log-prob = (v - max) - logf((float)sum) with the sum
+// of expf(v - max) accumulated in float64; top-k by (log-prob desc, class asc); candidates are (double)lp > thresh.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void beam_thresholds_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+                                                              int P, int64_t M, int k, double cand_thresh,
+                                                              int want_candidates, float* __restrict__ row_thr,
+                                                              int32_t* __restrict__ emit_cnt) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    // k largest part maxima (multiset), kept sorted descending in registers / scratch (k <= kBeamMaxK)
+    float top[kBeamMaxK];
+#pragma unroll
+    for (int i = 0; i < kBeamMaxK; ++i) top[i] = -INFINITY;
+    float gmax = -INFINITY;
+    for (int p = 0; p < P; ++p) {
+        float v = pmax[(int64_t)p * M + m];
+        gmax = fmaxf(gmax, v);
+#pragma unroll
+        for (int i = 0; i < kBeamMaxK; ++i) {              // insertion: v sinks to its place, the smallest drops out
+            if (i < k) {
+                const float t = top[i];
+                const bool sw = v > t;
+                top[i] = sw ? v : t;
+                v = sw ? t : v;
+            }
+        }
+    }
+    float tau = INFINITY;
+#pragma unroll
+    for (int i = 0; i < kBeamMaxK; ++i)
+        if (i == k - 1) tau = top[i];
+    // every top-k logit of the row is >= the k-th largest part maximum; a hair below it, so that a class whose
+    // log-prob ROUNDS to the k-th one's (and would win the tie on its lower index) is listed as well
+    float vmin = tau - 1e-5f * fmaxf(1.f, fabsf(tau));
+    if (want_candidates) {
+        // value bound of the candidate lists: log-prob > cand_thresh <=> v > max + log(sum) + thresh; the sum
+        // estimated from the per-part sums (relative error ~1e-6) and the bound lowered by 1e-3 so that the exact
+        // test in beam_select_kernel sees a superset
+        double sum = 0.0;
+        for (int p = 0; p < P; ++p)
+            sum += (double)psum[(int64_t)p * M + m] * exp((double)pmax[(int64_t)p * M + m] - (double)gmax);
+        const float vb = (float)((double)gmax + log(sum) + cand_thresh - 1e-3);
+        vmin = fminf(vmin, vb);
+    }
+    row_thr[2 * m] = vmin;
+    row_thr[2 * m + 1] = gmax;
+    emit_cnt[m] = 0;
+}
+
+hipError_t launch_beam_thresholds(const float* pmax, const float* psum, int P, int64_t M, int k, double cand_thresh,
+                                  int want_candidates, float* row_thr, int32_t* emit_cnt, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    if (k < 1 || k > kBeamMaxK || k > P) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(beam_thresholds_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, pmax, psum, P, M, k,
+                       cand_thresh, want_candidates, row_thr, emit_cnt);
+    return hipGetLastError();
+}
+
+// one wave per row m = b*W + t; outputs at r = t*B + b
+__global__ __launch_bounds__(256) void beam_select_kernel(const float* __restrict__ row_thr, const int32_t* __restrict__ emit_cnt,
+                                                          const int32_t* __restrict__ emit_list, int cap,
+                                                          const double* __restrict__ esum, int P,
+                                                          const float* __restrict__ blank_logit, int B, int W, int k,
+                                                          double cand_thresh, int32_t* __restrict__ topk_idx,
+                                                          float* __restrict__ topk_logp, float* __restrict__ blank_logp,
+                                                          float* __restrict__ stats, int32_t* __restrict__ cand_count,
+                                                          int32_t* __restrict__ overflow) {
+    const int lane = threadIdx.x & 63;
+    const int64_t M = (int64_t)B * W;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int b = (int)(m / W), t = (int)(m % W);
+    const int64_t r = (int64_t)t * B + b;
+    const int cnt = emit_cnt[m];
+    if (cnt > cap && lane == 0) atomicExch(overflow, 1);
+    const int n = cnt < cap ? cnt : cap;
+    const float gmax = row_thr[2 * m + 1];
+    double sum = 0.0;                                       // fixed order over the parts
+    for (int p = 0; p < P; ++p) sum += esum[(int64_t)p * M + m];
+    const float logs = logf((float)sum);
+    const int32_t* e = emit_list + (int64_t)m * cap * 2;
+    int c_above = 0;
+    for (int i = lane; i < n; i += 64) {
+        const float lp = (__builtin_bit_cast(float, e[2 * i + 1]) - gmax) - logs;
+        c_above += ((double)lp > cand_thresh) ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c_above += __shfl_xor(c_above, off);
+    if (lane == 0) {
+        blank_logp[r] = (blank_logit[m] - gmax) - logs;
+        if (stats) { stats[2 * r] = gmax; stats[2 * r + 1] = logs; }
+        if (cand_count) cand_count[r] = c_above;
+    }
+    // k selection rounds over the listed classes, (log-prob desc, class asc) like row_topk_kernel
+    float pv = INFINITY;
+    int pi = -1;
+    for (int j = 0; j < k; ++j) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = lane; i < n; i += 64) {
+            const int cls = e[2 * i];
+            const float lp = (__builtin_bit_cast(float, e[2 * i + 1]) - gmax) - logs;
+            const bool after = (lp < pv) || (lp == pv && cls > pi);
+            if (after && (lp > bv || (lp == bv && cls < bi))) { bv = lp; bi = cls; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            argmax_merge(bv, bi, ov, oi);
+        }
+        pv = bv; pi = bi;
+        if (lane == 0) {
+            topk_idx[r * k + j] = (bi == 0x7fffffff) ? 0 : bi;
+            topk_logp[r * k + j] = bv;
+        }
+    }
+}
+
+hipError_t launch_beam_select(const float* row_thr, const int32_t* emit_cnt, const int32_t* emit_list, int cap,
+                              const double* esum, int P, const float* blank_logit, int B, int W, int k,
+                              double cand_thresh, int32_t* topk_idx, float* topk_logp, float* blank_logp,
+                              float* stats, int32_t* cand_count, int32_t* overflow, hipStream_t s) {
+    const int64_t M = (int64_t)B * W;
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(beam_select_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, row_thr, emit_cnt, emit_list, cap,
+                       esum, P, blank_logit, B, W, k, cand_thresh, topk_idx, topk_logp, blank_logp, stats, cand_count,
+                       overflow);
+    return hipGetLastError();
+}
+
+// one wave per row: the listed classes whose log-prob exceeds the threshold, in ascending class order (np.where,
+// utils/ctc_codec.py:144), written to the row's CSR slot
+__global__ __launch_bounds__(256) void beam_candidates_kernel(const int32_t* __restrict__ emit_cnt,
+                                                              const int32_t* __restrict__ emit_list, int cap,
+                                                              const float* __restrict__ stats, int B, int W,
+                                                              double cand_thresh, const int64_t* __restrict__ cand_off,
+                                                              int32_t* __restrict__ cand_idx, float* __restrict__ cand_logp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t M = (int64_t)B * W;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int b = (int)(m / W), t = (int)(m % W);
+    const int64_t r = (int64_t)t * B + b;
+    const int cnt = emit_cnt[m];
+    const int n = cnt < cap ? cnt : cap;
+    const float gmax = stats[2 * r], logs = stats[2 * r + 1];
+    const int32_t* e = emit_list + (int64_t)m * cap * 2;
+    const int64_t base = cand_off[r];
+    for (int i = lane; i < n; i += 64) {
+        const int cls = e[2 * i];
+        const float lp = (__builtin_bit_cast(float, e[2 * i + 1]) - gmax) - logs;
+        if (!((double)lp > cand_thresh)) continue;
+        int rank = 0;                                       // candidates with a smaller class come first
+        for (int u = 0; u < n; ++u) {
+            const float lu = (__builtin_bit_cast(float, e[2 * u + 1]) - gmax) - logs;
+            rank += ((double)lu > cand_thresh && e[2 * u] < cls) ? 1 : 0;
+        }
+        cand_idx[base + rank] = cls;
+        cand_logp[base + rank] = lp;
+    }
+}
+
+hipError_t launch_beam_candidates(const int32_t* emit_cnt, const int32_t* emit_list, int cap, const float* stats,
+                                  int B, int W, double cand_thresh, const int64_t* cand_off, int32_t* cand_idx,
+                                  float* cand_logp, hipStream_t s) {
+    const int64_t M = (int64_t)B * W;
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(beam_candidates_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, emit_cnt, emit_list, cap, stats,
+                       B, W, cand_thresh, cand_off, cand_idx, cand_logp);
     return hipGetLastError();
 }
 

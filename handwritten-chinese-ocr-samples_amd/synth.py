@@ -109,12 +109,18 @@ def _load_calib():
     return _CALIB_CACHE["v"]
 
 
-def make_state_dict(num_classes=DEFAULT_VOCAB + 2, seed=0, diversified=True, calib="auto"):
+def make_state_dict(num_classes=DEFAULT_VOCAB + 2, seed=0, diversified=True, calib="auto", head="random"):
     """Full 254-entry state dict (numpy arrays, reference key schema).
 
     ``calib="auto"`` loads the committed trained-like BN statistics
     (``synth_bn_calib.npz``, produced by tests/golden/calibrate_synth_bn.py for seed 0)
     and perturbs them per seed; ``calib=None`` draws arbitrary statistics instead.
+
+    ``head="random"`` (default): heavy-tailed random classifier - its logits have a near-tie in about one
+    column of eight, which no reduced-precision path can decode identically to fp32. ``head="trained"``: the
+    classifier rows of the glyph-font classes (``make_font_lines``) come from ``synth_head_trained.npz``, a
+    ridge-regression read-out fitted on this same trunk's features (tools/fit_trained_head.py), so the logits on
+    font lines are peaky like a trained CTC model's; seed 0 / the default vocabulary only.
     """
     cal = _load_calib() if (calib == "auto" and diversified) else None
     sd = {}
@@ -158,9 +164,31 @@ def make_state_dict(num_classes=DEFAULT_VOCAB + 2, seed=0, diversified=True, cal
         b = (b.astype(np.float64) - w.astype(np.float64) @ cal["feat_mean"].astype(np.float64))
         b = b.astype(np.float32)
     b[0] += np.float32(HEAD_BLANK_BIAS)
+    if head == "trained":
+        if seed != 0 or num_classes != DEFAULT_VOCAB + 2 or cal is None:
+            raise ValueError("the trained-like head exists for seed 0 and the default vocabulary only")
+        th = _load_trained_head()
+        # classes outside the font: small random rows far below the fitted ones (they never win a column)
+        w = (w * np.float32(0.05)).astype(np.float32)
+        b = (_u(seed, "linear.bias", (num_classes,), -0.5, 0.5) - np.float32(8.0)).astype(np.float32)
+        rows = np.array([0] + [font_label(k) for k in range(th["w"].shape[0] - 1)], dtype=np.int64)   # row 0 = <blank>
+        w[rows] = th["w"].astype(np.float32)
+        b[rows] = th["b"].astype(np.float32)
+    elif head != "random":
+        raise ValueError("head must be 'random' or 'trained'")
     sd["linear.weight"] = w
     sd["linear.bias"] = b.astype(np.float32)
     return sd
+
+
+def _load_trained_head():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "synth_head_trained.npz")
+    if "head" not in _CALIB_CACHE:
+        if not os.path.isfile(path):
+            raise FileNotFoundError(path + " missing: run tools/fit_trained_head.py")
+        with np.load(path, allow_pickle=False) as z:
+            _CALIB_CACHE["head"] = {k: z[k] for k in z.files}
+    return _CALIB_CACHE["head"]
 
 
 HEAD_SCALE = 0.35
@@ -208,6 +236,79 @@ def make_line_images(batch, width, seed, line_offset=0):
         noise = (uniform01(st, 7, IMG_H * width) * 13.0).astype(np.int16).reshape(IMG_H, width) - 6
         imgs[b] += noise
     return np.clip(imgs, 0, 255).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------
+# glyph-font lines: the same stroke drawing, but every glyph is one of FONT_CLASSES fixed shapes, so a line
+# has a ground-truth label string and a read-out fitted on trunk features can recognise it
+# ---------------------------------------------------------------------------
+FONT_CLASSES = 8              # what a linear read-out of the RANDOM trunk's 2048 features separates cleanly
+FONT_SEED = 0x51F0            # (tools/fit_trained_head.py: 8 classes decode at 2.6 % CER vs the truth, 32 at 26 %)
+
+
+def font_label(k):
+    """label id (index into ``characters()`` + 1) of font class k: spread over the whole vocabulary / every head tile"""
+    return 1 + (int(k) * 919 + 3) % DEFAULT_VOCAB
+
+
+_FONT_CACHE = {}
+
+
+def font_glyph(k):
+    """(width, [(ax, ay, bx, by, thickness, value)]) of font class k; coordinates relative to the glyph box"""
+    if k not in _FONT_CACHE:
+        r = uniform01(FONT_SEED, 1000 + int(k), 128)
+        gw = 40 + int(r[0] * 50)
+        nseg = 6 + int(r[1] * 9)
+        segs = []
+        for i in range(nseg):
+            q = r[2 + 6 * i:8 + 6 * i]
+            segs.append((float(q[0]) * gw, 16 + float(q[1]) * 96, float(q[2]) * gw, 16 + float(q[3]) * 96,
+                         1.0 + float(q[4]) * 1.5, int(q[5] * 96)))
+        _FONT_CACHE[k] = (gw, segs)
+    return _FONT_CACHE[k]
+
+
+def make_font_lines(batch, width, seed, line_offset=0, with_truth=False, n_classes=FONT_CLASSES):
+    """uint8 [B,128,W] lines made of font glyphs (deterministic per (seed, line)). With ``with_truth`` also returns,
+    per line, the list of (class k, x0, x1) boxes in drawing order (glyphs cut by the right edge included)."""
+    imgs = np.full((batch, IMG_H, width), 255, dtype=np.int16)
+    yy = np.arange(IMG_H, dtype=np.float32)[:, None]
+    truth = []
+    for b in range(batch):
+        line = line_offset + b
+        st = ((int(seed) << 20) ^ line) + 0x7F000000
+        r = uniform01(st, 1, 512)
+        ri = 0
+        x = 4 + int(r[ri] * 20); ri += 1
+        boxes = []
+        while x < width - 8:
+            k = int(r[ri] * n_classes) % n_classes; ri += 1
+            gw, segs = font_glyph(k)
+            x0g, x1g = x, min(width, x + gw)
+            xx = np.arange(x0g, x1g, dtype=np.float32)[None, :]
+            for ax, ay, bx, by, th, val in segs:
+                ax, bx = x0g + ax, x0g + bx
+                dx, dy = bx - ax, by - ay
+                den = dx * dx + dy * dy + 1e-3
+                t = np.clip(((xx - ax) * dx + (yy - ay) * dy) / den, 0.0, 1.0)
+                d2 = (xx - ax - t * dx) ** 2 + (yy - ay - t * dy) ** 2
+                m = d2 <= th * th
+                sub = imgs[b, :, x0g:x1g]
+                sub[m] = np.minimum(sub[m], val)
+            boxes.append((k, x0g, x0g + gw))
+            x += gw + int(r[ri] * 12); ri += 1
+        noise = (uniform01(st, 7, IMG_H * width) * 13.0).astype(np.int16).reshape(IMG_H, width) - 6
+        imgs[b] += noise
+        truth.append(boxes)
+    out = np.clip(imgs, 0, 255).astype(np.uint8)
+    return (out, truth) if with_truth else out
+
+
+def font_truth_text(boxes, width, chars=None):
+    """label string of a line: every glyph whose box lies completely inside the image"""
+    chars = chars or characters()
+    return "".join(chars[font_label(k) - 1] for k, x0, x1 in boxes if x1 <= width)
 
 
 def normalize_pad(images_u8, widths=None, max_w=None):

@@ -827,3 +827,71 @@ def test_config2_all_64_lines_against_the_real_reference(engine, engine_x3, code
     for b in range(64):                                       # every line without a sub-2e-4 near-tie is EXACT
         if (margin[b] > 2e-4).all():
             assert text3[b] == ref_text[b], b
+
+
+def test_fused_beam_front_end_equals_stored_logits_path(pkg, engine, synth, state_dict):
+    """The beam front end without stored logits (head GEMM twice with reducing epilogues, kernels.h ConvArgs) against
+    the stored-logits kernels (row_topk / row_candidates on the engine's own logits): top-k classes, log-probs, blank
+    log-prob and the p > 0.001 candidate lists must be IDENTICAL (same float32 arithmetic, ties by lower class)."""
+    from importlib import import_module
+    model_mod = import_module(pkg.__name__ + ".model")
+    C = synth.DEFAULT_VOCAB + 2
+    for seed, widths, k in ((5, [200, 200, 200], 10), (52, [131, 100, 64, 17], 10), (6, [90], 32), (7, [48, 33], 3)):
+        imgs = synth.make_line_images(len(widths), max(widths), seed)
+        B, W = imgs.shape[0], imgs.shape[2]
+        fe = engine.beam_frontend(imgs, k=k, widths=widths, want_candidates=True)          # fused
+        logits = engine(imgs, widths=widths)                                                # [W,B,C] on the host
+        ref = model_mod.beam_frontend_call(engine._ctx, None, 0, 0, None, np.ascontiguousarray(logits), 0, B, W, C, k, True)
+        assert np.array_equal(fe["topk_idx"], ref["topk_idx"]), (seed, k)
+        assert np.array_equal(fe["topk_logp"], ref["topk_logp"]), (seed, k)
+        assert np.array_equal(fe["blank_logp"], ref["blank_logp"])
+        assert np.array_equal(fe["cand_off"], ref["cand_off"])
+        n = int(fe["cand_off"][-1])
+        assert n > 0 and np.array_equal(fe["cand_idx"][:n], ref["cand_idx"][:n])
+        assert np.array_equal(fe["cand_logp"][:n], ref["cand_logp"][:n])
+    # k beyond the fused path's limit is served by the stored-logits kernels
+    imgs = synth.make_line_images(1, 40, 8)
+    fe = engine.beam_frontend(imgs, k=40)
+    assert fe["topk_idx"].shape == (40, 1, 40) and (np.diff(fe["topk_logp"], axis=2) <= 0).all()
+    # near-uniform logits overflow the per-row lists: the pass is redone through the stored logits, same results
+    sd = dict(state_dict)
+    sd["linear.weight"] = np.zeros_like(state_dict["linear.weight"])
+    sd["linear.bias"] = np.full_like(state_dict["linear.bias"], 0.25)
+    flat = pkg.hctr_model(C).cuda(0)
+    flat.load_state_dict(sd)
+    fe = flat.beam_frontend(imgs, k=10, want_candidates=True)
+    assert np.array_equal(fe["topk_idx"][0, 0], np.arange(10))                # all equal: lowest classes first
+    assert np.allclose(fe["topk_logp"], -np.log(C), atol=1e-4) and int(fe["cand_off"][-1]) == 0
+
+
+def test_trained_like_checkpoint_text_exact_in_both_modes(pkg, synth):
+    """north_star's "decoded text exact" on BASELINE configs[1] (64 x 1x128x2000): with the trained-like checkpoint
+    (synth.make_state_dict(head="trained"): logits peaky like a trained CTC model's, margins in
+    tests/golden/c2_trained_lines.json) the greedy text of ALL 64 lines equals the REAL reference's (fp32 CPU) in the
+    default f16 mode - the mode bench.py times - and in f16x3. Logit tolerances as everywhere: f16 0.01*scale + 0.05,
+    f16x3 2e-4*scale; argmax identical on every column whose reference margin exceeds twice the mode's tolerance."""
+    with open(os.path.join(GOLDEN, "c2_trained_lines.json"), encoding="utf-8") as f:
+        meta = json.load(f)
+    g = np.load(os.path.join(GOLDEN, "c2_trained_lines.npz"))
+    ref_arg, margin = g["argmax"].astype(np.int64), g["margin"]
+    scale = float(np.abs(g["max"]).max())
+    C = synth.DEFAULT_VOCAB + 2
+    sd = synth.make_state_dict(C, seed=0, head="trained")
+    imgs = synth.make_font_lines(64, meta["width"], meta["seed"])
+    cd = pkg.ctc_codec(synth.characters())
+    for mode, tol in (("f16", f16_tol(scale)), ("f16x3", X3_RTOL * scale)):
+        m = pkg.hctr_model(C, precision=mode).cuda(0)
+        m.load_state_dict(sd)
+        text = cd.labels_to_text(m.greedy(imgs))
+        assert text == meta["greedy"], (mode, sum(a != b for a, b in zip(text, meta["greedy"])))
+        arg = np.zeros_like(ref_arg)
+        mx = np.zeros_like(g["max"])
+        for s0 in range(0, 64, 8):
+            lg = m(imgs[s0:s0 + 8])
+            arg[s0:s0 + 8] = lg.argmax(axis=2).T
+            mx[s0:s0 + 8] = lg.max(axis=2).T
+        assert float(np.abs(mx - g["max"]).max()) <= tol, mode
+        safe = margin > 2 * tol
+        assert safe.mean() >= 0.999 and np.array_equal(arg[safe], ref_arg[safe]), mode
+        assert (arg != ref_arg).sum() <= 8, mode
+        del m

@@ -135,3 +135,42 @@ def test_oracle_matches_reference_extra_fixtures(synth, state_dict, name, seed, 
             oc.lm_panelty, oc.len_bonus, oc.beam_size, oc.search_depth = lp, lb, bs, depth
             oc.ngram = ctc_ref.ZeroLM() if lm == "zero" else ctc_ref.ToyBigramLM()
             assert oc.decode(logits) == strings[tag], tag
+
+
+@pytest.mark.parametrize("which,line", [("random", 5), ("trained", 11)])
+def test_oracle_matches_reference_on_config2_lines(synth, state_dict, which, line):
+    """One full-width (W=2000) line of BASELINE configs[1] per checkpoint: the oracle forward + codec against the REAL
+    reference's per-column outputs (tests/golden/c2_lines.* / c2_trained_lines.*, all 64 lines; one is re-run here)."""
+    base = "c2_lines" if which == "random" else "c2_trained_lines"
+    with open(os.path.join(GOLDEN, base + ".json"), encoding="utf-8") as f:
+        meta = json.load(f)
+    g = np.load(os.path.join(GOLDEN, base + ".npz"))
+    C = synth.DEFAULT_VOCAB + 2
+    if which == "random":
+        sd, imgs = state_dict, synth.make_line_images(1, meta["width"], meta["seed"], line_offset=line)
+    else:
+        sd = synth.make_state_dict(C, seed=0, head="trained")
+        imgs = synth.make_font_lines(1, meta["width"], meta["seed"], line_offset=line)
+    logits = hctr_ref.forward(sd, synth.normalize_pad(imgs)).numpy()[:, 0, :]
+    np.testing.assert_allclose(logits.max(axis=1), g["max"][line], atol=3 * LOGIT_ATOL, rtol=0)
+    safe = g["margin"][line] > 4 * LOGIT_ATOL
+    assert safe.mean() > 0.99
+    assert np.array_equal(logits.argmax(axis=1)[safe], g["argmax"][line][safe].astype(np.int64))
+    if safe.all():
+        assert ctc_ref.CtcCodecRef(synth.characters()).decode(logits[:, None, :])[0] == meta["greedy"][line]
+
+
+def test_trained_checkpoint_fixture_is_peaky(synth):
+    """The trained-like checkpoint's reason to exist, stated on the REAL reference's outputs: top-2 margins far above any
+    reduced-precision logit error (f16: <= 1 % of the logit scale), and the reference reads the font lines nearly
+    right (its greedy text vs the lines' ground truth)."""
+    with open(os.path.join(GOLDEN, "c2_trained_lines.json"), encoding="utf-8") as f:
+        meta = json.load(f)
+    g = np.load(os.path.join(GOLDEN, "c2_trained_lines.npz"))
+    scale = float(np.abs(g["max"]).max())
+    margin = g["margin"]
+    assert (margin < 0.02 * scale).sum() <= 40                       # of 128 000 columns (random head: ~17 000)
+    assert margin.min() > 0.002 * scale
+    _, truth = synth.make_font_lines(64, meta["width"], meta["seed"], with_truth=True)
+    edits = sum(ctc_ref.edit_distance(t, synth.font_truth_text(b, meta["width"])) for t, b in zip(meta["greedy"], truth))
+    assert edits <= 0.05 * sum(len(t) for t in meta["greedy"])

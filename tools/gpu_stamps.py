@@ -70,3 +70,20 @@ gaps = np.array(gaps)
 print("  slot gap (end of a workgroup -> entry of the next in that CU): median %.2f us  p10 %.2f  p90 %.2f" %
       (np.median(gaps), np.percentile(gaps, 10), np.percentile(gaps, 90)))
 print("  workgroups per CU: min %d  median %d  max %d" % (min(conc), int(np.median(conc)), max(conc)))
+
+# ---- how the two workgroups of a CU are phased: share of the layer's span during which 0 / 1 / 2 of a CU's resident
+# workgroups are inside their K loop (stamps 2..3). Lockstep tiles leave the matrix pipe idle whenever both are outside.
+span0, span1 = t[:, 0].min(), t[:, 5].max()
+occ = np.zeros(3)
+for k in np.unique(key):
+    idx = np.where(key == k)[0]
+    ev = [(t[i, 2], 1) for i in idx] + [(t[i, 3], -1) for i in idx]
+    ev.sort()
+    cur, last = 0, span0
+    for tm, d in ev:
+        occ[min(cur, 2)] += tm - last
+        cur += d
+        last = tm
+    occ[min(cur, 2)] += span1 - last
+occ /= occ.sum()
+print("  CU time with 0 / 1 / 2 workgroups in the K loop: %.3f / %.3f / %.3f" % tuple(occ))
