@@ -123,6 +123,7 @@ struct hctr_ctx {
     int64_t stamp_cap = 0, stamp_n = 0;
     bool fuse_ds = true;             // 1x1 downsample inside conv2's K loop (HCTR_FUSE_DS=0: own launch + residual)
     bool fuse_argmax = true;         // greedy: argmax in the head GEMM's epilogue (HCTR_FUSE_ARGMAX=0: separate pass)
+    bool fuse_stem = true;           // conv0_1 inside conv0_2's loader (HCTR_FUSE_STEM=0: own launch + 16 kB/column buffer)
     bool fuse_beam = true;           // beam front end without stored logits (HCTR_FUSE_BEAM=0: logits + row_topk)
     int64_t beam_fallbacks = 0;      // passes that overflowed a row list and were redone through the logits
     // profiling
@@ -411,7 +412,7 @@ int ensure_workspace(hctr_ctx* c, int B, int W) {
         };
         A((char**)&ws.img, (size_t)cols * kImgH * 4, false);
         A(&ws.widths, (size_t)B, false);
-        A(&ws.s0, (size_t)act_elems(B, 128, Wa, 64 * m), true);
+        // ws.s0 (conv0_1's output, 16 kB per column) only exists on the unfused / f16x3 stem path (ensure_s0)
         int cin = 64;
         size_t se_max = 0;
         for (int s = 1; s <= 4; ++s) {
@@ -463,6 +464,17 @@ int ensure_logits(hctr_ctx* c) {
         return fail(c, HCTR_ERR_STATE, "no active workspace");
     Workspace& slot = c->ws_cache.front();          // the active workspace is the cache's first entry
     TRY(dev_alloc(c, slot.allocs, &slot.logits, (size_t)slot.B * slot.W * c->cpad, false, &slot.bytes));
+    c->ws = slot;
+    return HCTR_OK;
+}
+
+// conv0_1's output buffer for the unfused stem (HCTR_FUSE_STEM=0, f16x3): zero-filled once (stored conv borders)
+int ensure_s0(hctr_ctx* c) {
+    if (c->ws.s0) return HCTR_OK;
+    if (c->ws_cache.empty() || c->ws_cache.front().B != c->ws.B || c->ws_cache.front().W != c->ws.W)
+        return fail(c, HCTR_ERR_STATE, "no active workspace");
+    Workspace& slot = c->ws_cache.front();
+    TRY(dev_alloc(c, slot.allocs, &slot.s0, (size_t)act_elems(slot.B, 128, slot.Wa, 64 * c->chm()), true, &slot.bytes));
     c->ws = slot;
     return HCTR_OK;
 }
@@ -541,7 +553,8 @@ ConvTile pick_tile(const hctr_ctx* c, const ConvW& cw, int H) {
 
 int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc in, half_t* out, int outH,
              bool relu, bool pool, float* se_part, bool to_head, const float* se_scale = nullptr,
-             const half_t* resid = nullptr, const ConvW* ds = nullptr, const half_t* ds_in = nullptr) {
+             const half_t* resid = nullptr, const ConvW* ds = nullptr, const half_t* ds_in = nullptr,
+             int stem_img_f32 = -1, bool stem_widths = false) {
     const Workspace& ws = c->ws;
     ConvArgs a{};
     a.x = in.p; a.w = cw.w; a.bias = cw.bias; a.y = out; a.se_part = se_part;
@@ -586,7 +599,15 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
         c->stamp_n = (int64_t)a.mtiles * a.ntiles;
     }
     pf.begin(name);
-    HIP_TRY(c, launch_conv(a, tile, cw.taps, false, c->stream));
+    if (stem_img_f32 >= 0) {      // conv0_2 with conv0_1 computed in its loader from the staged image (kernels.hip)
+        if (tile != TILE_64x256 || cw.taps != 9 || cw.cin != 64 || cw.coutPad != 64 || c->split)
+            return fail(c, HCTR_ERR_STATE, "conv %s: stem fusion not applicable", name);
+        a.img = ws.img; a.img_f32 = stem_img_f32; a.img_widths = stem_widths ? ws.widths : nullptr;
+        a.stem_w = c->stem_w; a.stem_b = c->stem_b;
+        HIP_TRY(c, launch_stem_conv0_2(a, c->stream));
+    } else {
+        HIP_TRY(c, launch_conv(a, tile, cw.taps, false, c->stream));
+    }
     pf.end();
     return HCTR_OK;
 }
@@ -670,11 +691,18 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths, HeadMode mode = HEAD
     if (mode == HEAD_BEAM) TRY(ensure_beam_ws(c));
     Workspace& ws = c->ws;
     Prof pf(c);
-    pf.begin("stem.conv0_1");
-    HIP_TRY(c, launch_stem(ws.img, img_f32, have_widths ? ws.widths : nullptr, c->stem_w, c->stem_b, ws.s0, ws.B,
-                           ws.W, ws.Wa, c->split, c->stream));
-    pf.end();
-    TRY(run_conv(c, pf, "conv0_2+pool", c->conv0_2, ActDesc{ws.s0, 128, 64}, ws.x[1], 64, true, true, nullptr, false));
+    if (c->fuse_stem && !c->split) {
+        // conv0_1's output (16 kB per pixel column) never reaches HBM: it is computed into conv0_2's LDS halo
+        TRY(run_conv(c, pf, "stem+conv0_2+pool", c->conv0_2, ActDesc{nullptr, 128, 64}, ws.x[1], 64, true, true, nullptr,
+                     false, nullptr, nullptr, nullptr, nullptr, img_f32 ? 1 : 0, have_widths));
+    } else {
+        TRY(ensure_s0(c));
+        pf.begin("stem.conv0_1");
+        HIP_TRY(c, launch_stem(ws.img, img_f32, have_widths ? ws.widths : nullptr, c->stem_w, c->stem_b, ws.s0, ws.B,
+                               ws.W, ws.Wa, c->split, c->stream));
+        pf.end();
+        TRY(run_conv(c, pf, "conv0_2+pool", c->conv0_2, ActDesc{ws.s0, 128, 64}, ws.x[1], 64, true, true, nullptr, false));
+    }
     int cin = 64;
     for (int s = 1; s <= 4; ++s) {
         const int H = kStageH[s], planes = kStagePlanes[s - 1];
@@ -834,6 +862,7 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
         if (const char* fa = getenv("HCTR_FUSE_ARGMAX")) c->fuse_argmax = atoi(fa) != 0;
         if (const char* fd = getenv("HCTR_FUSE_DS")) c->fuse_ds = atoi(fd) != 0;
         if (const char* fb = getenv("HCTR_FUSE_BEAM")) c->fuse_beam = atoi(fb) != 0;
+        if (const char* fs2 = getenv("HCTR_FUSE_STEM")) c->fuse_stem = atoi(fs2) != 0;
         if (const char* wb = getenv("HCTR_WS_BUDGET_GB")) {
             const long long v = atoll(wb);
             if (v > 0) c->ws_budget = (size_t)v << 30;
@@ -1396,7 +1425,10 @@ int64_t hctr_debug_activation(hctr_ctx* c, const char* name, float* out, int64_t
         int H = 0, C = 0;
         bool head = false;
         const std::string n(name);
-        if (n == "conv0_1") { p = ws.s0; H = 128; C = 64; }
+        if (n == "conv0_1") {
+            if (!ws.s0) return fail(c, HCTR_ERR_STATE, "conv0_1 is fused into conv0_2 (no buffer): use HCTR_FUSE_STEM=0");
+            p = ws.s0; H = 128; C = 64;
+        }
         else if (n == "stage0") { p = ws.x[1]; H = 64; C = 64; }
         else if (n == "stage1") { p = ws.x[2]; H = 32; C = 128; }
         else if (n == "stage2") { p = ws.x[3]; H = 16; C = 256; }

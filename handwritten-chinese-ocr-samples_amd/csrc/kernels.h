@@ -54,6 +54,13 @@ struct ConvArgs {
     int32_t* emit_list;       // [M][emit_cap][2] = {class, float bits}
     int emit_cap;
     double* esum;             // [P][M]
+    // launch_stem_conv0_2 only: the raw line images (u8 [B][128][W] or f32 [B][1][128][W]), each line's valid width
+    // (NULL = W) and conv0_1's folded fp32 weights [64][9] / bias [64]; x is unused there
+    const void* img;
+    int img_f32;
+    const int32_t* img_widths;
+    const float* stem_w;
+    const float* stem_b;
     int split;              // f16x3 mode: activations are [hi | lo | hi] fp16 planes of Cout channels each
                             // (input side: Cin already counts the tripled channels)
     // fused 1x1 downsample of a block's input (first block of stages 1-3): the halo4 kernel first accumulates
@@ -87,6 +94,10 @@ constexpr int kLinearWN = 2;          // wave columns of both linear-mode tiles 
 // rows [P][M] of (value, class) partials -> idx[M]: first maximum, 0 for an all-(-inf)/NaN row
 hipError_t launch_argmax_partials(const float* val, const int32_t* cls, int P, int64_t M, int32_t* idx, hipStream_t s);
 size_t conv_lds_bytes(ConvTile tile);
+
+// NormalizePAD + conv0_1 + bn0_1 + ReLU computed into the LDS halo of conv0_2's tile, then conv0_2 + bn0_2 + ReLU +
+// (2,1) max-pool from it: conv0_1's 16 kB-per-column output never exists in HBM (f16 mode; a.w/bias = conv0_2's)
+hipError_t launch_stem_conv0_2(const ConvArgs& a, hipStream_t s);
 
 hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, const float* w9,
                        const float* bias, half_t* y, int B, int W, int Wa, int split, hipStream_t s);

@@ -1391,6 +1391,166 @@ hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, 
 }
 
 // -------------------------------------------------------------------------------------------
+// stem_conv0_2: the two stem convolutions in one kernel (models/handwritten_ctr_model.py:116-123 with NormalizePAD,
+// utils/dataset.py:83-93, in front). conv0_1 (1 -> 64 channels) is HBM-bound when it runs alone: 128 B in, 16 kB out
+// per pixel column, which conv0_2 reads straight back. Here a workgroup computes conv0_1 + bn0_1 + ReLU for the
+// 18 x 18-pixel halo of its 16 x 16 output tile from a 20 x 20 patch of the image (fp32 FMAs in the order of
+// stem_kernel: the halo holds bit for bit what that kernel stores) and writes it into the swizzled LDS halo image of
+// the halo kernels; conv0_2 + bn0_2 + ReLU + (2,1) max-pool then run as 9 taps of MFMAs from it. Weights of conv0_2
+// (9 taps x 64 couts x 64 cin) stream in 2-tap pieces of 16 KB through two buffers.
+// 4 waves, each 64 couts x (4 rows x 16 columns); LDS 2 x 16 KB + 45 KB + 1.6 KB patch: two workgroups per CU, so
+// one's conv0_1 arithmetic (VALU) overlaps the other's MFMAs.
+// -------------------------------------------------------------------------------------------
+constexpr int kS2Halo = 32768;                       // LDS offsets
+constexpr int kS2Patch = 32768 + kHaloBytes;
+constexpr int kS2Lds = kS2Patch + 20 * 20 * 4;       // 80448
+
+__global__ __launch_bounds__(256, 2) void stem_conv0_2_kernel(const ConvArgs a) {
+    constexpr int JT = 4, S = kHaloCols;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = a.mtiles;
+    int lin;
+    {
+        const int id = blockIdx.x, xcd = id & 7, sl = id >> 3;
+        const int qd = total >> 3, r = total & 7;
+        lin = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + sl;
+    }
+    const int tw = lin % a.tilesW;
+    const int t2 = lin / a.tilesW;
+    const int th = t2 % a.tilesH;
+    const int img = t2 / a.tilesH;
+    const int W = a.W;
+
+    // ---- conv0_2 weights of K step st (taps 2st, 2st+1; the last step has one tap): 16 one-KiB pieces, 4 per wave ----
+    auto stage_w = [&](int st, int buf) {
+        const char* src = (const char*)a.w + (size_t)st * (2 * 64 * 64 * 2);
+        char* dst = smem + buf * 16384 + (wv * 4) * 1024;
+        const int npieces = st == 4 ? 8 : 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wv * 4 + i;
+            if (piece < npieces) {                                  // wave-uniform
+                const int g = piece * 64 + lane;
+                const int row = g >> 3, cp = (g & 7) ^ (row & 7);
+                glds16_asm(src + (uint32_t)row * 128u + cp * 16, dst + i * 1024);
+            }
+        }
+    };
+    stage_w(0, 0);
+
+    // ---- 20 x 20 patch of the normalised image (zero outside the image: conv0_1's padding; columns >= the line's
+    //      width replicate its last column: NormalizePAD) ----
+    float* patch = (float*)(smem + kS2Patch);
+    {
+        const int wlim = a.img_widths ? a.img_widths[img] : W;
+        for (int e = tid; e < 400; e += 256) {
+            const int py = e / 20, px = e - py * 20;
+            const int hh = th * 16 - 2 + py, ww = tw * 16 - 2 + px;
+            float v = 0.f;
+            if (hh >= 0 && hh < 128 && ww >= 0 && ww < W) {
+                const int wsrc = ww < wlim ? ww : wlim - 1;
+                const int64_t off = ((int64_t)img * 128 + hh) * W + wsrc;
+                if (a.img_f32) {
+                    v = ((const float*)a.img)[off];
+                } else {
+                    const float x = (float)((const uint8_t*)a.img)[off] / 255.0f;
+                    v = (x - 0.5f) / 0.5f;
+                }
+            }
+            patch[e] = v;
+        }
+    }
+    // conv0_1 weights of this thread's 8-channel group
+    const int cg = tid & 7;
+    float wt[8][9], bs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bs[e] = a.stem_b[cg * 8 + e];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[e][t] = a.stem_w[(cg * 8 + e) * 9 + t];
+    }
+    __syncthreads();
+    // ---- conv0_1 + bn0_1 + ReLU into the halo: unit = (halo pixel, 8 channels) -> one 16-byte LDS store ----
+    for (int u = tid >> 3; u < kHaloRows * 18; u += 32) {
+        const int hy = u / 18, hx = u - hy * 18;
+        const int r = th * 16 - 1 + hy, col = tw * 16 - 1 + hx;       // image position of this conv0_1 output
+        f16x8 o;
+        if (r >= 0 && r < 128 && col >= 0 && col < W) {
+            float win[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) win[t] = patch[(hy + t / 3) * 20 + hx + t % 3];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float sv = bs[e];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) sv = fmaf(wt[e][t], win[t], sv);
+                o[e] = (half_t)fmaxf(sv, 0.f);
+            }
+        } else {                                                       // conv0_2's zero padding / columns >= W
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)0.f;
+        }
+        const int hr = hy * S + hx;
+        *(f16x8*)(smem + kS2Halo + hr * 128 + ((cg ^ (hr & 7)) << 4)) = o;
+    }
+
+    // ---- conv0_2: 9 taps x 2 k-slices; a wave owns 64 couts x (rows wv*4.. +3) x 16 columns ----
+    const int q = lane >> 4, c = lane & 15;
+    const int aoff0 = c * 128 + (((0 + q) ^ (lane & 7)) << 4);
+    const int aoff1 = c * 128 + (((4 + q) ^ (lane & 7)) << 4);
+    const int wrow = wv * 4;
+    f32x4 acc[JT][4];
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int st = 0; st < 5; ++st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's weight pieces of step st have landed
+        __syncthreads();                                               // ... everyone's, and (st == 0) the halo is written
+        if (st + 1 < 5) stage_w(st + 1, (st + 1) & 1);
+        const int ntap = st == 4 ? 1 : 2;
+        for (int tt = 0; tt < ntap; ++tt) {
+            const int tap = st * 2 + tt;
+            const int tdy = tap / 3, dx = tap - tdy * 3 - 1;
+            const int u = c + 1 + dx;
+            const int v0 = u * 128 + (((q ^ (u & 7) ^ ((tdy & 1) << 2)) & 7) << 4);
+            const char* hb = smem + kS2Halo + (wrow + tdy) * (S * 128);
+            const char* be = hb + v0;
+            const char* bo = hb + (v0 ^ 64);
+            const char* wtile = smem + (st & 1) * 16384 + tt * 8192;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 af[JT], bf[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bf[n] = *(const f16x8*)((((n & 1) ^ ks) ? bo : be) + n * (S * 128));
+#pragma unroll
+                for (int j = 0; j < JT; ++j) af[j] = *(const f16x8*)(wtile + j * 2048 + (ks ? aoff1 : aoff0));
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], bf[n], acc[j][n], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+    }
+    conv_epilogue<1, 4, JT, false, false>(a, acc, smem, tid, lane, 0, wv, 0, lin, img, th, tw, th * 16 + wrow, tw * 16);
+}
+
+hipError_t launch_stem_conv0_2(const ConvArgs& a, hipStream_t s) {
+    if (a.mtiles == 0) return hipSuccess;
+    static bool done[64] = {};
+    hipError_t e0 = raise_lds_limit((const void*)stem_conv0_2_kernel, kS2Lds, done);
+    if (e0 != hipSuccess) return e0;
+    hipLaunchKernelGGL(stem_conv0_2_kernel, dim3(a.mtiles), dim3(256), kS2Lds, s, a);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------
 // Squeeze-excite mean WITHOUT materialising conv2's output first.
 // SELayer needs mean_{h,w}(bn2(conv2(t))) (models/handwritten_ctr_model.py:27,51-53). The convolution is
 // linear, so with S_tap[ci] = sum over output positions of t[h+dy][w+dx][ci] (zero outside the image)

@@ -140,9 +140,24 @@ def test_forward_matches_f16_oracle(engine, synth, state_dict, seed, widths):
         assert (diff > 0).mean() <= 0.03, what
 
     x = torch.from_numpy(synth.normalize_pad(imgs, widths))
+    # the stem as two launches (HCTR_FUSE_STEM=0: conv0_1 stored, generic 64x256 MFMA conv with fused pool), layer by
+    # layer; then the default fused kernel (conv0_1 computed into conv0_2's LDS halo) must reproduce it BIT FOR BIT
+    default_engine = engine
+    os.environ["HCTR_FUSE_STEM"] = "0"
+    try:
+        engine = type(default_engine)(synth.DEFAULT_VOCAB + 2).cuda(0)
+    finally:
+        del os.environ["HCTR_FUSE_STEM"]
+    engine.load_state_dict(state_dict)
+    assert np.array_equal(engine(imgs, widths=widths), got)
     check_layer(None, "conv0_1", "cnn.conv0_1", "cnn.bn0_1", False, "stem", half_weights=False, x_in=x)
-    # MFMA conv, 64x256 tile, fused pool: from the engine's own conv0_1
     check_layer("conv0_1", "stage0", "cnn.conv0_2", "cnn.bn0_2", True, "conv0_2+pool")
+    unfused_stage0 = engine.debug_activation("stage0", B)
+    engine = default_engine
+    engine(imgs, widths=widths)
+    assert np.array_equal(engine.debug_activation("stage0", B), unfused_stage0)
+    with pytest.raises(RuntimeError):
+        engine.debug_activation("conv0_1", B)                      # fused: that tensor never exists
     # MFMA conv, 128x128 tile: block1.1.conv1 from the engine's own block1.0 output (buffer p1.1)
     check_layer("p1.1", "p1.2", "cnn.block1.1.conv1", "cnn.block1.1.bn1", False, "block1.1.conv1")
     # MFMA conv, 256x256 tile: block2.3.conv1 (p2.0) from block2.2's output (p2.2); block3.4.conv1
@@ -552,7 +567,8 @@ def test_full_size_config2_properties(engine, codec, synth):
 
 @pytest.mark.parametrize("env", [{"HCTR_HALO": "0"}, {"HCTR_HALO": "1"}, {"HCTR_HALO": "0", "HCTR_PIPE": "1"},
                                  {"HCTR_FUSE_SE": "0"}, {"HCTR_HALO": "0", "HCTR_BIG_TILES": "0"},
-                                 {"HCTR_PERSIST": "1"}, {"HCTR_FUSE_ARGMAX": "0"}, {"HCTR_FUSE_DS": "0"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+                                 {"HCTR_PERSIST": "1"}, {"HCTR_FUSE_ARGMAX": "0"}, {"HCTR_FUSE_DS": "0"},
+                                 {"HCTR_FUSE_STEM": "0"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_alternative_kernel_paths(env):
     """The A/B kernels (generic 64x256/128x128/256x256 tiles, 8-wave halo, interleaved pipe, unfused SE,
     persistent tiles) stay correct: same fixture and tolerances as the default path. Kernel selection is
@@ -740,7 +756,7 @@ def test_kernel_families_agree_over_random_shapes(tmp_path):
     tool = os.path.join(ROOT, "tools", "gpu_shape_sweep.py")
     a, b = str(tmp_path / "a.npz"), str(tmp_path / "b.npz")
     base = {k: v for k, v in os.environ.items() if not k.startswith("HCTR_")}
-    for path, extra in ((a, {}), (b, {"HCTR_HALO": "0", "HCTR_FUSE_SE": "0", "HCTR_FUSE_DS": "0", "HCTR_FUSE_ARGMAX": "0"})):
+    for path, extra in ((a, {}), (b, {"HCTR_HALO": "0", "HCTR_FUSE_SE": "0", "HCTR_FUSE_DS": "0", "HCTR_FUSE_ARGMAX": "0", "HCTR_FUSE_STEM": "0"})):
         env = dict(base)
         env.update(extra)
         r = subprocess.run([sys.executable, tool, "dump", path], env=env, capture_output=True, text=True, timeout=900)
