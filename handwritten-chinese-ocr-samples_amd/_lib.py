@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libhctr_hip.so")
 HEADER = os.path.join(ROOT, "include", "hctr_hip.h")
 
 # (source, extra flags). beam_search.cpp must not contract a*b+c (bit-parity with Python floats).
-SOURCES = [("kernels.hip", []), ("preprocess.hip", ["-ffp-contract=off"]), ("engine.cpp", ["-x", "hip"]), ("beam_search.cpp", ["-ffp-contract=off"]),
+SOURCES = [("gather.cpp", ["-x", "hip"]), ("kernels.hip", []), ("preprocess.hip", ["-ffp-contract=off"]), ("engine.cpp", ["-x", "hip"]), ("beam_search.cpp", ["-ffp-contract=off"]),
            ("ngram_lm.cpp", ["-ffp-contract=off"])]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -112,7 +112,7 @@ def _build_locked(verbose):
         with open(tagfile, "w") as f:
             f.write(tag)
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-lpthread"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-lpthread", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
@@ -165,6 +165,11 @@ SIGNATURES = [
     ("hctr_ngram_word_id", ctypes.c_int32, [_VP, ctypes.c_char_p]),
     ("hctr_ngram_score", ctypes.c_double, [_VP, ctypes.c_char_p, _I, _I]),
     ("hctr_ngram_last_error", ctypes.c_char_p, []),
+    ("hctr_comm_unique_id", _I, [_VP]),
+    ("hctr_comm_create", _I, [ctypes.POINTER(_VP), _VP, _I, _I, _I]),
+    ("hctr_comm_destroy", None, [_VP]),
+    ("hctr_gather_labels", _I, [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
+    ("hctr_comm_last_error", ctypes.c_char_p, []),
     ("hctr_resize_lines", _I, [_VP, _VP, _I64, c_i64p, c_i32p, c_i32p, c_i32p, _I, _I, c_i32p, _I, _VP, _I]),
     ("hctr_set_profiling", _I, [_VP, _I]),
     ("hctr_last_profile", _I, [_VP, ctypes.c_char_p, _I, c_f32p, _I]),

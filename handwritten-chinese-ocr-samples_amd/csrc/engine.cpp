@@ -66,6 +66,7 @@ struct Workspace {
     float* se_scale = nullptr;
     float* se_border = nullptr;     // [B][4][8 segments][512]
     float* se_mean = nullptr;       // [B][512]
+    int32_t* se_counter = nullptr;  // [B] last-block-done tickets of se_premean (zero between launches)
     int32_t* colidx = nullptr;      // [B*W]
     float* amax_val = nullptr;      // [P][B*W] fused head argmax partials, P <= Cpad/64
     int32_t* amax_idx = nullptr;
@@ -428,8 +429,9 @@ int ensure_workspace(hctr_ctx* c, int B, int W) {
         // paths need it (ensure_logits)
         A(&ws.se_part, se_max, false);
         A(&ws.se_scale, (size_t)B * 512, false);
-        A(&ws.se_border, (size_t)B * 4 * 8 * 512, false);
+        A(&ws.se_border, (size_t)B * 5 * 8 * 512, false);
         A(&ws.se_mean, (size_t)B * 512, false);
+        A(&ws.se_counter, (size_t)B, true);
         A(&ws.colidx, (size_t)cols, false);
         A(&ws.amax_val, (size_t)cols * (c->cpad / 64), false);
         A(&ws.amax_idx, (size_t)cols * (c->cpad / 64), false);
@@ -637,15 +639,13 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
     if (c->fuse_se || c->split) {
         const int tiles1 = tiles_of(bw.conv1);
         TRY(run_conv(c, pf, (name + ".conv1").c_str(), bw.conv1, in, t, H, true, false, ws.se_part, false));
-        pf.begin((name + ".se_border").c_str());
-        HIP_TRY(c, launch_se_border(t, ws.B, H, ws.W, ws.Wa, planes, c->split, ws.se_border, c->stream));
+        pf.begin((name + ".se_stats").c_str());
+        HIP_TRY(c, launch_se_border(t, ws.B, H, ws.W, ws.Wa, planes, c->split, ws.se_part, tiles1, ws.se_border, c->stream));
         pf.end();
-        pf.begin((name + ".se_premean").c_str());
-        HIP_TRY(c, launch_se_premean(ws.se_part, tiles1, ws.se_border, t, bw.conv2.w, bw.conv2.bias, ws.B, H, ws.W,
-                                     ws.Wa, planes, bw.conv2.coutPad, c->split, ws.se_mean, c->stream));
-        pf.end();
-        pf.begin((name + ".se_fc").c_str());
-        HIP_TRY(c, launch_se_fc(ws.se_mean, 1, bw.se.w1, bw.se.w2, ws.se_scale, ws.B, planes, 1.0f, c->stream));
+        pf.begin((name + ".se_scale").c_str());
+        HIP_TRY(c, launch_se_premean(ws.se_border, t, bw.conv2.w, bw.conv2.bias, ws.B, H, ws.W, ws.Wa, planes,
+                                     bw.conv2.coutPad, c->split, ws.se_mean, bw.se.w1, bw.se.w2, ws.se_scale,
+                                     ws.se_counter, c->stream));
         pf.end();
         if (fuse_ds)
             TRY(run_conv(c, pf, (name + ".conv2+se+ds").c_str(), bw.conv2, ActDesc{t, H, planes}, o, H, true, false,

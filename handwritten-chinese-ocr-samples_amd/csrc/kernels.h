@@ -102,14 +102,15 @@ hipError_t launch_stem_conv0_2(const ConvArgs& a, hipStream_t s);
 hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, const float* w9,
                        const float* bias, half_t* y, int B, int W, int Wa, int split, hipStream_t s);
 
-// channel sums of the border rows / columns of a padded NHWC activation: out[b][4][C] =
-// {row 0, row H-1, column 0, column W-1}
-hipError_t launch_se_border(const half_t* t, int B, int H, int W, int Wa, int C, int split, float* out,
-                            hipStream_t s);
-// SE mean of conv2(t) from the statistics of t (linearity of the convolution), see kernels.hip
-hipError_t launch_se_premean(const float* tsum_part, int tiles, const float* border, const half_t* t,
-                             const half_t* w, const float* bias, int B, int H, int W, int Wa, int C,
-                             int CoutPad, int split, float* mean, hipStream_t s);
+// statistics of a padded NHWC activation t for the fused squeeze-excite: out[b][5][8 segments][C] = channel sums of
+// {row 0, row H-1, column 0, column W-1, the whole image}; the whole-image sums come from conv1's per-tile sums
+hipError_t launch_se_border(const half_t* t, int B, int H, int W, int Wa, int C, int split, const float* tsum_part,
+                            int tiles, float* out, hipStream_t s);
+// SE mean of conv2(t) from those statistics (linearity of the convolution) and, by the last block of each image,
+// the SELayer FCs -> channel scales; counter: int32 [B], zero before the first launch (the kernel re-zeroes it)
+hipError_t launch_se_premean(const float* border, const half_t* t, const half_t* w, const float* bias, int B, int H,
+                             int W, int Wa, int C, int CoutPad, int split, float* mean, const float* w1,
+                             const float* w2, float* scale, int32_t* counter, hipStream_t s);
 
 hipError_t launch_se_fc(const float* se_part, int tiles_per_img, const float* w1, const float* w2,
                         float* scale, int B, int C, float inv_hw, hipStream_t s);

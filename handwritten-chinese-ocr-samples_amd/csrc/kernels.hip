@@ -1565,10 +1565,26 @@ hipError_t launch_stem_conv0_2(const ConvArgs& a, hipStream_t s) {
 constexpr int kBorderSeg = 8;       // each border line is summed by 8 blocks (partials reduced in se_premean)
 
 __global__ __launch_bounds__(256) void se_border_kernel(const half_t* __restrict__ t, int H, int W, int Wa, int C,
-                                                        int split, float* __restrict__ out) {
+                                                        int split, const float* __restrict__ tsum_part, int tiles,
+                                                        float* __restrict__ out) {
     __shared__ float red[256 * 8];
-    const int b = blockIdx.x, job = blockIdx.y;        // 0: row 0, 1: row H-1, 2: col 0, 3: col W-1
+    const int b = blockIdx.x, job = blockIdx.y;        // 0: row 0, 1: row H-1, 2: col 0, 3: col W-1, 4: whole-image total
     const int seg = blockIdx.z;
+    if (job == 4) {
+        // T = sum over the image of t, from conv1's per-tile sums [b][tile][C]: this block adds the tiles of its
+        // segment in order (se_premean adds the 8 segment sums in order: fixed association, bit-reproducible)
+        const int per = (tiles + kBorderSeg - 1) / kBorderSeg;
+        const int t0 = seg * per, t1 = t0 + per < tiles ? t0 + per : tiles;
+        for (int ci = threadIdx.x; ci < C; ci += 256) {
+            const float* p = tsum_part + (int64_t)b * tiles * C + ci;
+            float s0 = 0.f, s1 = 0.f;
+            int i = t0;
+            for (; i + 1 < t1; i += 2) { s0 += p[(int64_t)i * C]; s1 += p[(int64_t)(i + 1) * C]; }
+            if (i < t1) s0 += p[(int64_t)i * C];
+            out[(((int64_t)b * 5 + 4) * kBorderSeg + seg) * C + ci] = s0 + s1;
+        }
+        return;
+    }
     const int cv = C >> 3;                             // 16-byte vectors per pixel
     const int v = threadIdx.x % cv, lanes = 256 / cv, p0 = threadIdx.x / cv;
     const int cs = split ? 3 * C : C;                  // channels per pixel in memory
@@ -1601,48 +1617,44 @@ __global__ __launch_bounds__(256) void se_border_kernel(const half_t* __restrict
             for (int e = 0; e < 8; ++e) s[e] += red[(l * cv + threadIdx.x) * 8 + e];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            out[(((int64_t)b * 4 + job) * kBorderSeg + seg) * C + threadIdx.x * 8 + e] = s[e];
+            out[(((int64_t)b * 5 + job) * kBorderSeg + seg) * C + threadIdx.x * 8 + e] = s[e];
     }
 }
 
-hipError_t launch_se_border(const half_t* t, int B, int H, int W, int Wa, int C, int split, float* out,
-                            hipStream_t s) {
-    hipLaunchKernelGGL(se_border_kernel, dim3(B, 4, kBorderSeg), dim3(256), 0, s, t, H, W, Wa, C, split, out);
+hipError_t launch_se_border(const half_t* t, int B, int H, int W, int Wa, int C, int split, const float* tsum_part,
+                            int tiles, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(se_border_kernel, dim3(B, 5, kBorderSeg), dim3(256), 0, s, t, H, W, Wa, C, split, tsum_part, tiles, out);
     return hipGetLastError();
 }
 
-// one block per (image, 64 output channels); 4 k-slices x 64 couts per block
-__global__ __launch_bounds__(256) void se_premean_kernel(const float* __restrict__ tsum_part, int tiles,
-                                                         const float* __restrict__ border,
+// one block per (image, 64 output channels); 4 k-slices x 64 couts per block. The block that finishes an image LAST
+// (agent-scope counter per image) also runs the SELayer FCs on the completed means (models/handwritten_ctr_model.py:
+// 19-29) and writes the channel scales: one launch instead of two, and no second pass over the per-tile sums.
+__global__ __launch_bounds__(256) void se_premean_kernel(const float* __restrict__ border,
                                                          const half_t* __restrict__ t,
                                                          const half_t* __restrict__ w,
                                                          const float* __restrict__ bias, int H, int W, int Wa,
                                                          int C, int CoutPad, int split,
-                                                         float* __restrict__ mean) {
+                                                         float* __restrict__ mean, const float* __restrict__ w1,
+                                                         const float* __restrict__ w2, float* __restrict__ scale,
+                                                         int32_t* __restrict__ counter) {
     __shared__ float S[9 * 512];
+    __shared__ float part[256];
+    __shared__ int last_flag;
     const int b = blockIdx.x, cg = blockIdx.y;
     const int cs = split ? 3 * C : C;                  // channels per pixel / weight row length
     const half_t* img = t + (int64_t)b * (H + 2) * Wa * cs;
     for (int ci = threadIdx.x; ci < C; ci += 256) {
-        const float* p = tsum_part + (int64_t)b * tiles * C + ci;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int i = 0;
-        for (; i + 3 < tiles; i += 4) {
-            s0 += p[(int64_t)i * C]; s1 += p[(int64_t)(i + 1) * C];
-            s2 += p[(int64_t)(i + 2) * C]; s3 += p[(int64_t)(i + 3) * C];
-        }
-        for (; i < tiles; ++i) s0 += p[(int64_t)i * C];
-        const float T = (s0 + s1) + (s2 + s3);
-        float bsum[4];
+        float bsum[5];
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {               // fixed-order sum of the segment partials
-            const float* bd = border + (((int64_t)b * 4 + jb) * kBorderSeg) * C + ci;
+        for (int jb = 0; jb < 5; ++jb) {               // fixed-order sum of the segment partials
+            const float* bd = border + (((int64_t)b * 5 + jb) * kBorderSeg) * C + ci;
             float sv = 0.f;
 #pragma unroll
             for (int sg = 0; sg < kBorderSeg; ++sg) sv += bd[(int64_t)sg * C];
             bsum[jb] = sv;
         }
-        const float R0 = bsum[0], RL = bsum[1], C0 = bsum[2], CL = bsum[3];
+        const float R0 = bsum[0], RL = bsum[1], C0 = bsum[2], CL = bsum[3], T = bsum[4];
         auto px = [&](int hp, int wp) {
             const half_t* q = img + ((int64_t)hp * Wa + wp) * cs + ci;
             return split ? (float)q[0] + (float)q[C] : (float)q[0];
@@ -1683,7 +1695,6 @@ __global__ __launch_bounds__(256) void se_premean_kernel(const float* __restrict
             for (int e = 0; e < 8; ++e) acc = fmaf((float)wv8[e], S[tap * C + ci + e], acc);
         }
     }
-    __shared__ float part[256];
     part[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -1691,14 +1702,54 @@ __global__ __launch_bounds__(256) void se_premean_kernel(const float* __restrict
         const int c = cg * 64 + threadIdx.x;
         mean[(int64_t)b * C + c] = bias[c] + tot / ((float)H * (float)W);
     }
+    // ---- hand-off: the means of this block are published (every storing wave drains, barrier, agent-scope release),
+    //      then the image's counter is bumped; the block that draws the last ticket acquires and runs the FCs ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(counter + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == (int)gridDim.y - 1;
+        if (last) {
+            __hip_atomic_store(counter + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        last_flag = last;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    float* mean_s = S;                                 // (S is free again)
+    float* hid = S + 512;
+    for (int c = threadIdx.x; c < C; c += 256)
+        mean_s[c] = __hip_atomic_load(mean + (int64_t)b * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int R = C / 16;
+    {
+        const int r = threadIdx.x >> 3, l = threadIdx.x & 7;     // hidden: R <= 32 outputs, 8 lanes each
+        float sv = 0.f;
+        if (r < R)
+            for (int c = l; c < C; c += 8) sv = fmaf(w1[r * C + c], mean_s[c], sv);
+        sv += __shfl_xor(sv, 1);
+        sv += __shfl_xor(sv, 2);
+        sv += __shfl_xor(sv, 4);
+        if (r < R && l == 0) hid[r] = fmaxf(sv, 0.f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float sv = 0.f;
+        for (int r = 0; r < R; ++r) sv = fmaf(w2[c * R + r], hid[r], sv);
+        scale[(int64_t)b * C + c] = 1.f / (1.f + expf(-sv));
+    }
 }
 
-hipError_t launch_se_premean(const float* tsum_part, int tiles, const float* border, const half_t* t,
-                             const half_t* w, const float* bias, int B, int H, int W, int Wa, int C,
-                             int CoutPad, int split, float* mean, hipStream_t s) {
+hipError_t launch_se_premean(const float* border, const half_t* t, const half_t* w, const float* bias, int B, int H,
+                             int W, int Wa, int C, int CoutPad, int split, float* mean, const float* w1,
+                             const float* w2, float* scale, int32_t* counter, hipStream_t s) {
     if (C > 512 || C % 64 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(se_premean_kernel, dim3(B, C / 64), dim3(256), 0, s, tsum_part, tiles, border, t, w, bias, H, W,
-                       Wa, C, CoutPad, split, mean);
+    hipLaunchKernelGGL(se_premean_kernel, dim3(B, C / 64), dim3(256), 0, s, border, t, w, bias, H, W, Wa, C, CoutPad,
+                       split, mean, w1, w2, scale, counter);
     return hipGetLastError();
 }
 

@@ -189,6 +189,27 @@ int hctr_resize_lines(hctr_ctx* ctx, const uint8_t* packed_src, int64_t packed_b
                       const int32_t* heights, const int32_t* widths, const int32_t* channels, int n,
                       int out_height, const int32_t* out_widths, int out_W, uint8_t* out, int out_on_device);
 
+/* ---- multi-GPU result gather for plain-C callers -----------------------------------
+ * The path shards by lines: one process per GPU runs hctr_greedy on its contiguous range of the (globally padded)
+ * batch, and the decoded label sequences meet in ONE collective. The reference has no counterpart (single-device
+ * inference, test.py:143-148; NCCL only in training DDP, main.py:226-237). Python callers use torch.distributed
+ * (handwritten-chinese-ocr-samples_amd/dist.py); these entry points do the same over RCCL (xGMI), which is bound
+ * with dlopen at the first call. Protocol as in NCCL: rank 0 calls hctr_comm_unique_id and hands the 128 bytes to
+ * the other ranks out of band (file, socket, MPI); every rank then calls hctr_comm_create.
+ * hctr_gather_labels: every rank passes its n_local decoded lines (labels: int32 [n_local][row_stride], the first
+ * lengths[i] entries of row i valid - exactly hctr_greedy's outputs with row_stride = W) and the common
+ * lines_per_rank = ceil(global lines / world) and cap (longest label sequence allowed). One ncclAllGather of the
+ * packed [lines_per_rank][1 + cap] int32 buffer; on return EVERY rank holds out_labels int32 [world*lines_per_rank][cap]
+ * and out_lengths [world*lines_per_rank] in rank order (rows >= a rank's n_local have length 0). */
+#define HCTR_COMM_ID_BYTES 128
+typedef struct hctr_comm hctr_comm;
+int hctr_comm_unique_id(void* id128);
+int hctr_comm_create(hctr_comm** out, const void* id128, int rank, int world, int device);
+void hctr_comm_destroy(hctr_comm* comm);
+int hctr_gather_labels(hctr_comm* comm, const int32_t* labels, const int32_t* lengths, int n_local, int row_stride,
+                       int lines_per_rank, int cap, int32_t* out_labels, int32_t* out_lengths);
+const char* hctr_comm_last_error(void);
+
 /* ---- introspection used by bench.py / tests ---------------------------------------------------
  * Per-layer device time of the last forward (HIP events on the context's stream), in call order.
  * names: '\n'-separated layer names written into buf (cap bytes); ms: float array of n entries.

@@ -911,3 +911,33 @@ def test_trained_like_checkpoint_text_exact_in_both_modes(pkg, synth):
         assert safe.mean() >= 0.999 and np.array_equal(arg[safe], ref_arg[safe]), mode
         assert (arg != ref_arg).sum() <= 8, mode
         del m
+
+
+def test_c_abi_rccl_gather_world_1(pkg, engine, synth):
+    """hctr_comm_* / hctr_gather_labels (the plain-C caller's collective, include/hctr_hip.h): communicator over RCCL
+    with the one rank this box has, fed with hctr_greedy's own outputs; the gathered rows must equal the inputs and the
+    pad rows must come back empty. (World size 2 needs two GPUs: the N > 1 logic is covered over gloo.)"""
+    import ctypes
+    lib = pkg.load_library()
+    uid = ctypes.create_string_buffer(128)
+    assert lib.hctr_comm_unique_id(uid) == 0, lib.hctr_comm_last_error()
+    comm = ctypes.c_void_p()
+    assert lib.hctr_comm_create(ctypes.byref(comm), uid, 0, 1, 0) == 0, lib.hctr_comm_last_error()
+    try:
+        imgs = synth.make_line_images(3, 120, 9)
+        B, W = imgs.shape[0], imgs.shape[2]
+        labels = np.zeros((B, W), np.int32)
+        lengths = np.zeros((B,), np.int32)
+        _l = pkg._lib
+        _l.check(lib.hctr_greedy(engine._ctx, _l.ptr(imgs), _l.U8, 0, None, B, W, _l.ptr(labels), _l.ptr(lengths)), engine._ctx)
+        cap, per = int(lengths.max()), 4                         # one pad row: lines_per_rank = ceil(n / world) may exceed n_local
+        out_l = np.full((per, cap), -1, np.int32)
+        out_n = np.full((per,), -1, np.int32)
+        rc = lib.hctr_gather_labels(comm, _l.ptr(labels), _l.ptr(lengths), B, W, per, cap, _l.ptr(out_l), _l.ptr(out_n))
+        assert rc == 0, lib.hctr_comm_last_error()
+        assert out_n.tolist() == lengths.tolist() + [0]
+        for b in range(B):
+            assert np.array_equal(out_l[b, :lengths[b]], labels[b, :lengths[b]]) and not out_l[b, lengths[b]:].any()
+        assert lib.hctr_gather_labels(comm, _l.ptr(labels), _l.ptr(lengths), B, W, per, cap - 1, _l.ptr(out_l), _l.ptr(out_n)) == -1
+    finally:
+        lib.hctr_comm_destroy(comm)
