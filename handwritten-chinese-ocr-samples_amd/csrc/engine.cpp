@@ -587,7 +587,7 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
     }
     a.relu = relu; a.pool = pool;
     if (ds) {                 // fused 1x1 downsample of the block input (same H, W, Wa; ds->cin channels)
-        if (tile != TILE_HALO4 || c->split || !se_scale || resid || ds->cin % kBK != 0 || ds->coutPad != cw.coutPad)
+        if (tile != TILE_HALO4 || !se_scale || resid || ds->cin % kBK != 0 || ds->coutPad != cw.coutPad)
             return fail(c, HCTR_ERR_STATE, "conv %s: downsample fusion not applicable", name);
         a.ds_x = ds_in; a.ds_w = ds->w; a.ds_bias = ds->bias; a.ds_cin = ds->cin;
         a.ds_in_sh = ws.Wa * ds->cin;
@@ -630,7 +630,7 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
     const half_t* res = in.p;
     // first block of stages 1-3: the 1x1 downsample branch runs inside conv2's K loop (kernels.hip DSFUSE) when
     // conv2 is on the default halo kernel; otherwise (A/B paths, f16x3) as its own launch writing the residual r
-    const bool fuse_ds = bw.has_ds && c->fuse_ds && c->fuse_se && !c->split && bw.ds.cin % kBK == 0 &&
+    const bool fuse_ds = bw.has_ds && c->fuse_ds && (c->fuse_se || c->split) && bw.ds.cin % kBK == 0 &&
                          pick_tile(c, bw.conv2, H) == TILE_HALO4;
     if (bw.has_ds && !fuse_ds) {
         TRY(run_conv(c, pf, (name + ".downsample").c_str(), bw.ds, in, r, H, false, false, nullptr, false));

@@ -206,7 +206,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
     const int64_t pix0 = a.out_off + img * a.out_sb + (int64_t)w * a.out_sw + cw0;
 
     // fused squeeze-excite + residual (BasicBlock :54-58): acc = acc * scale[img][cout] + residual
-    if (SPLIT && a.se_scale != nullptr) {
+    if (SPLIT && !RESID_IN_ACC && a.se_scale != nullptr) {
         // f16x3: the residual is hi + lo (planes Cout apart); loaded per (cb, n), accuracy mode only
         const float* sc = a.se_scale + (int64_t)img * a.Cout + cw0;
         if (w < a.out_wlimit) {
@@ -877,7 +877,7 @@ constexpr int kHalo4Lds = 2 * 16384 + kHaloBytes;          // 78848
 // multiplies by s: s * (W2*t + b2) + (Wd*x + bd). The residual is neither written nor read back (4.2 GB per launch).
 template <int GEOM, bool SPLIT, bool PERSIST, bool STAMP = false, bool DSFUSE = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a) {
-    static_assert(!DSFUSE || (!PERSIST && !SPLIT), "downsample fusion: default f16 path only");
+    static_assert(!DSFUSE || !PERSIST, "downsample fusion: non-persistent instances only");
     constexpr int WN = 1, WM = 4, JT = 8, BN = 128;
     constexpr int TR = GEOM ? 8 : 16, TC = GEOM ? 32 : 16;       // tile rows / columns
     constexpr int S = TC + 4;                                      // halo row stride in pixels
@@ -1216,14 +1216,14 @@ static hipError_t launch_conv_halo4_tp(const ConvArgs& a0, hipStream_t s) {
 template <int GEOM, bool SPLIT>
 static hipError_t launch_conv_halo4_t(const ConvArgs& a, hipStream_t s) {
     if (a.ds_x != nullptr) {
-        if (GEOM != 0 || SPLIT) return hipErrorInvalidValue;      // (engine only fuses on the default f16 16x16 path)
+        if (GEOM != 0) return hipErrorInvalidValue;               // (the engine only fuses on the 16x16 geometry)
         static bool done_ds[64] = {};
-        hipError_t e0 = raise_lds_limit((const void*)conv3x3_halo4_kernel<0, false, false, false, true>, kHalo4LdsTotal, done_ds);
+        hipError_t e0 = raise_lds_limit((const void*)conv3x3_halo4_kernel<0, SPLIT, false, false, true>, kHalo4LdsTotal, done_ds);
         if (e0 != hipSuccess) return e0;
         static const int dbg = [] { const char* e = getenv("HCTR_DBG"); return e ? atoi(e) : 0; }();
         ConvArgs b = a;
         b.dbg = dbg;
-        hipLaunchKernelGGL((conv3x3_halo4_kernel<0, false, false, false, true>), dim3(a.mtiles * a.ntiles), dim3(256),
+        hipLaunchKernelGGL((conv3x3_halo4_kernel<0, SPLIT, false, false, true>), dim3(a.mtiles * a.ntiles), dim3(256),
                            kHalo4LdsTotal, s, b);
         return hipGetLastError();
     }

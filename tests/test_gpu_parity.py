@@ -941,3 +941,27 @@ def test_c_abi_rccl_gather_world_1(pkg, engine, synth):
         assert lib.hctr_gather_labels(comm, _l.ptr(labels), _l.ptr(lengths), B, W, per, cap - 1, _l.ptr(out_l), _l.ptr(out_n)) == -1
     finally:
         lib.hctr_comm_destroy(comm)
+
+
+def test_config5_beam_strings_equal_the_real_reference_end_to_end(pkg, synth):
+    """BASELINE configs[4] end to end against the REAL reference (its fp32 CPU forward followed by its own ctc_codec beam
+    search, tests/golden/c5_beam_lines.json from make_golden_c5.py): full-width trained-like-checkpoint lines through
+    the engine's f16 forward, the fused device front end (log-softmax, top-10, p > 0.001 lists) and the C++ host prefix
+    search must give the same strings - cbs_full with the toy-bigram and the zero LM, and cbs_skip (whose in-place
+    single-candidate updates make strings of ~380 characters on these lines: the reference's behaviour, reproduced)."""
+    with open(os.path.join(GOLDEN, "c5_beam_lines.json"), encoding="utf-8") as f:
+        gold = json.load(f)
+    C = synth.DEFAULT_VOCAB + 2
+    imgs = synth.make_font_lines(gold["lines"], gold["width"], gold["seed"])
+    for mode in ("f16", "f16x3"):
+        m = pkg.hctr_model(C, precision=mode).cuda(0)
+        m.load_state_dict(synth.make_state_dict(C, seed=0, head="trained"))
+        cd = pkg.ctc_codec(synth.characters()).attach(m)
+        assert cd.labels_to_text(m.greedy(imgs)) == gold["greedy"], mode
+        for tag, skip, lm in (("full_toy", False, pkg.ToyBigramLM()), ("full_zero", False, pkg.ZeroLM()),
+                              ("skip_toy", True, pkg.ToyBigramLM())):
+            cd.use_beam_search, cd.skip_search, cd.use_tfm_pred, cd.use_tfm_score = True, skip, False, False
+            cd.lm_panelty, cd.len_bonus, cd.beam_size, cd.search_depth, cd.ngram = 0.8, 4.8, 10, 10, lm
+            fe = m.beam_frontend(imgs, k=10, want_candidates=skip)
+            assert cd.decode_frontend(fe) == gold[tag], (mode, tag)
+        del cd, m
