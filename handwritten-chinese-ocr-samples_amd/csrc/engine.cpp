@@ -72,7 +72,7 @@ struct Workspace {
     int32_t* amax_idx = nullptr;
     int32_t* labels = nullptr;      // [B][W]
     int32_t* lengths = nullptr;     // [B]
-    // fused beam front end (allocated on first use, ensure_beam_ws): see ConvArgs in kernels.h
+    // fused beam front end (WS_BEAM, carved on first use): see ConvArgs in kernels.h
     float* psum = nullptr;          // [P][B*W]
     float* blank_logit = nullptr;   // [B*W]
     float* row_thr = nullptr;       // [B*W][2]
@@ -80,9 +80,11 @@ struct Workspace {
     int32_t* emit_list = nullptr;   // [B*W][kBeamCap][2]
     double* esum = nullptr;         // [P][B*W]
     int32_t* overflow = nullptr;    // [1]
-    std::vector<void*> allocs;
-    size_t bytes = 0;
+    int features = 0;               // WS_* sets carved into this layout
 };
+
+// optional parts of a workspace layout (carved behind the core buffers, so adding one moves nothing)
+enum WsFeature { WS_S0 = 1, WS_LOGITS = 2, WS_BEAM = 4 };
 
 struct ProfEntry {
     std::string name;
@@ -107,9 +109,14 @@ struct hctr_ctx {
     ConvW stage_conv[4];
     ConvW head;
     std::vector<void*> wallocs;
-    Workspace ws;                       // the active workspace (a copy of one cache entry's pointers)
-    std::vector<Workspace> ws_cache;    // workspaces by (B, W), least recently used last
-    size_t ws_budget = (size_t)200 << 30;
+    // ONE device arena holds the workspace of whatever (lines, width) shape is active: a new shape re-carves the
+    // pointers and re-zeroes the stored conv borders (a small kernel), it does not allocate - ragged workloads present a
+    // new padded width with almost every batch. The arena grows to the largest layout seen.
+    Workspace ws;
+    char* arena = nullptr;
+    size_t arena_cap = 0;
+    int ws_sticky = 0;                  // optional parts this context has needed so far (kept in later layouts)
+    int64_t arena_reallocs = 0, ws_recarves = 0;
     int64_t max_cols = kDefaultMaxCols;
     bool big_tiles = true;
     int halo_mode = 2;
@@ -376,132 +383,99 @@ int build_head(hctr_ctx* c) {
 // ---------------------------------------------------------------------------------------------
 inline int64_t act_elems(int B, int H, int Wa, int C) { return (int64_t)B * (H + 2) * Wa * C; }
 
-int ensure_workspace(hctr_ctx* c, int B, int W) {
-    if (c->ws.B == B && c->ws.W == W) return HCTR_OK;
-    // look in the cache (bucketed workloads alternate between a few (B, W) shapes; each workspace is
-    // tens of GB and must be zero-filled once so the stored conv borders are valid)
-    for (size_t i = 0; i < c->ws_cache.size(); ++i)
-        if (c->ws_cache[i].B == B && c->ws_cache[i].W == W) {
-            Workspace w = c->ws_cache[i];
-            c->ws_cache.erase(c->ws_cache.begin() + i);
-            c->ws_cache.insert(c->ws_cache.begin(), w);
-            c->ws = w;
-            return HCTR_OK;
-        }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+int ensure_workspace(hctr_ctx* c, int B, int W, int features = 0) {
+    c->ws_sticky |= features;
+    if (c->ws.B == B && c->ws.W == W && (c->ws.features & c->ws_sticky) == c->ws_sticky) return HCTR_OK;
+    const bool same_shape = c->ws.B == B && c->ws.W == W;
+    const int feat = c->ws_sticky;
     Workspace ws;
-    ws.B = B; ws.W = W;
+    ws.B = B; ws.W = W; ws.features = feat;
     const int tilesW = (W + kTileW - 1) / kTileW;        // 16-column tiles (upper bound on tiles per row)
     const int Wa = (W + 31) / 32 * 32 + 2;               // room for the widest (32-column) tile + border
     ws.Wa = Wa;
-    const int64_t cols = (int64_t)B * W;
-    // estimate, then evict least-recently-used workspaces until the new one fits the budget
-    const size_t need = (size_t)cols * 300000 * c->chm();
-    while (!c->ws_cache.empty()) {
-        size_t used = 0;
-        for (auto& w : c->ws_cache) used += w.bytes;
-        if (used + need <= c->ws_budget) break;
-        free_pool(c->ws_cache.back().allocs);
-        c->ws_cache.pop_back();
-    }
-    c->ws = Workspace();
+    const size_t cols = (size_t)B * W;
     const int m = c->chm();
-    auto alloc_all = [&]() {
-        int rc = HCTR_OK;
-        auto A = [&](auto** out, size_t count, bool zero) {
-            if (rc == HCTR_OK) rc = dev_alloc(c, ws.allocs, out, count, zero, &ws.bytes);
-        };
-        A((char**)&ws.img, (size_t)cols * kImgH * 4, false);
-        A(&ws.widths, (size_t)B, false);
-        // ws.s0 (conv0_1's output, 16 kB per column) only exists on the unfused / f16x3 stem path (ensure_s0)
-        int cin = 64;
-        size_t se_max = 0;
+    // ---- layout: byte offsets into the arena, 256-byte aligned; core buffers first, optional parts behind them ----
+    size_t off = 0;
+    std::vector<std::pair<void**, size_t>> slots;
+    auto A = [&](auto** out, size_t count) {
+        slots.emplace_back((void**)out, off);
+        off += (std::max<size_t>(count * sizeof(**out), 16) + 255) & ~(size_t)255;
+    };
+    A((char**)&ws.img, cols * kImgH * 4);
+    A(&ws.widths, (size_t)B);
+    int cin = 64;
+    size_t se_max = 0;
+    for (int s = 1; s <= 4; ++s) {
+        const int H = kStageH[s], planes = kStagePlanes[s - 1];
+        A(&ws.x[s], (size_t)act_elems(B, H, Wa, cin * m));
+        const int nbuf = (s == 4) ? 2 : 3;
+        for (int i = 0; i < nbuf; ++i) A(&ws.p[s][i], (size_t)act_elems(B, H, Wa, planes * m));
+        se_max = std::max(se_max, (size_t)B * (H / 8) * tilesW * planes);
+        cin = planes;
+    }
+    A(&ws.headin, cols * kFeat * m);
+    A(&ws.se_part, se_max);
+    A(&ws.se_scale, (size_t)B * 512);
+    A(&ws.se_border, (size_t)B * 5 * 8 * 512);
+    A(&ws.se_mean, (size_t)B * 512);
+    A(&ws.se_counter, (size_t)B);
+    A(&ws.colidx, cols);
+    A(&ws.amax_val, cols * (c->cpad / 64));
+    A(&ws.amax_idx, cols * (c->cpad / 64));
+    A(&ws.labels, cols);
+    A(&ws.lengths, (size_t)B);
+    // conv0_1's output (16 kB per column): only the unfused / f16x3 stem path
+    if (feat & WS_S0) A(&ws.s0, (size_t)act_elems(B, 128, Wa, 64 * m));
+    // [B*W][cpad] fp32 logits (3.8 GB at config 2): hctr_forward_logits and the HCTR_FUSE_* = 0 A/B paths only
+    if (feat & WS_LOGITS) A(&ws.logits, cols * c->cpad);
+    if (feat & WS_BEAM) {                                // scratch of the fused beam front end (kernels.h ConvArgs)
+        const size_t P = (size_t)c->cpad / 128;
+        A(&ws.psum, P * cols);
+        A(&ws.blank_logit, cols);
+        A(&ws.row_thr, 2 * cols);
+        A(&ws.emit_cnt, cols);
+        A(&ws.esum, P * cols);
+        A(&ws.overflow, (size_t)1);
+        A(&ws.emit_list, cols * kBeamCap * 2);
+    }
+    bool fresh = false;
+    if (off > c->arena_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->arena) (void)hipFree(c->arena);
+        c->arena = nullptr; c->arena_cap = 0;
+        c->ws = Workspace();
+        const size_t want = off + off / 16;              // a little headroom: the next slightly wider batch fits too
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) e = hipMalloc(&p, off);
+        if (e != hipSuccess)
+            return fail(c, HCTR_ERR_NOMEM, "hipMalloc(%zu bytes) for the workspace of %d lines x %d columns failed: %s", off,
+                        B, W, hipGetErrorString(e));
+        c->arena = (char*)p;
+        c->arena_cap = e == hipSuccess && want >= off ? want : off;
+        ++c->arena_reallocs;
+        fresh = true;
+    }
+    for (auto& sl : slots) *sl.first = c->arena + sl.second;
+    // ---- stored conv borders: every activation buffer's border rows / columns must read as zero. The interiors are
+    //      rewritten by each forward, so after a shape change (or a new arena) only the borders are cleared. ----
+    auto zero_act = [&](half_t* p, int H, int C) { return launch_zero_borders(p, B, H, W, Wa, C * m, c->stream); };
+    if (fresh || !same_shape) {
+        int ci = 64;
         for (int s = 1; s <= 4; ++s) {
             const int H = kStageH[s], planes = kStagePlanes[s - 1];
-            A(&ws.x[s], (size_t)act_elems(B, H, Wa, cin * m), true);
+            HIP_TRY(c, zero_act(ws.x[s], H, ci));
             const int nbuf = (s == 4) ? 2 : 3;
-            for (int i = 0; i < nbuf; ++i) A(&ws.p[s][i], (size_t)act_elems(B, H, Wa, planes * m), true);
-            se_max = std::max(se_max, (size_t)B * (H / 8) * tilesW * planes);
-            cin = planes;
+            for (int i = 0; i < nbuf; ++i) HIP_TRY(c, zero_act(ws.p[s][i], H, planes));
+            ci = planes;
         }
-        A(&ws.headin, (size_t)cols * kFeat * m, false);
-        // ws.logits ([B*W][cpad] fp32, 3.8 GB at config 2) is NOT allocated here: only the API-parity and unfused
-        // paths need it (ensure_logits)
-        A(&ws.se_part, se_max, false);
-        A(&ws.se_scale, (size_t)B * 512, false);
-        A(&ws.se_border, (size_t)B * 5 * 8 * 512, false);
-        A(&ws.se_mean, (size_t)B * 512, false);
-        A(&ws.se_counter, (size_t)B, true);
-        A(&ws.colidx, (size_t)cols, false);
-        A(&ws.amax_val, (size_t)cols * (c->cpad / 64), false);
-        A(&ws.amax_idx, (size_t)cols * (c->cpad / 64), false);
-        A(&ws.labels, (size_t)cols, false);
-        A(&ws.lengths, (size_t)B, false);
-        return rc;
-    };
-    int rc = alloc_all();
-    if (rc == HCTR_ERR_NOMEM && !c->ws_cache.empty()) {
-        // the budget estimate was too optimistic for what the device has free: drop every cached workspace, retry once
-        free_pool(ws.allocs);
-        ws = Workspace();
-        ws.B = B; ws.W = W; ws.Wa = Wa;
-        for (auto& w : c->ws_cache) free_pool(w.allocs);
-        c->ws_cache.clear();
-        rc = alloc_all();
+        HIP_TRY(c, hipMemsetAsync(ws.se_counter, 0, (size_t)B * 4, c->stream));
+        ++c->ws_recarves;
     }
-    if (rc != HCTR_OK) {
-        free_pool(ws.allocs);
-        return rc;
-    }
-    c->ws_cache.insert(c->ws_cache.begin(), ws);
+    if (ws.s0 && (fresh || !same_shape || !c->ws.s0)) HIP_TRY(c, zero_act(ws.s0, 128, 64));
     c->ws = ws;
     return HCTR_OK;
-}
-
-// [B*W][cpad] fp32 logits of the active workspace, allocated on first use (hctr_forward_logits, caller-visible
-// log-probabilities, the HCTR_FUSE_* = 0 A/B paths). The fused greedy and beam paths never touch them.
-int ensure_logits(hctr_ctx* c) {
-    if (c->ws.logits) return HCTR_OK;
-    if (c->ws_cache.empty() || c->ws_cache.front().B != c->ws.B || c->ws_cache.front().W != c->ws.W)
-        return fail(c, HCTR_ERR_STATE, "no active workspace");
-    Workspace& slot = c->ws_cache.front();          // the active workspace is the cache's first entry
-    TRY(dev_alloc(c, slot.allocs, &slot.logits, (size_t)slot.B * slot.W * c->cpad, false, &slot.bytes));
-    c->ws = slot;
-    return HCTR_OK;
-}
-
-// conv0_1's output buffer for the unfused stem (HCTR_FUSE_STEM=0, f16x3): zero-filled once (stored conv borders)
-int ensure_s0(hctr_ctx* c) {
-    if (c->ws.s0) return HCTR_OK;
-    if (c->ws_cache.empty() || c->ws_cache.front().B != c->ws.B || c->ws_cache.front().W != c->ws.W)
-        return fail(c, HCTR_ERR_STATE, "no active workspace");
-    Workspace& slot = c->ws_cache.front();
-    TRY(dev_alloc(c, slot.allocs, &slot.s0, (size_t)act_elems(slot.B, 128, slot.Wa, 64 * c->chm()), true, &slot.bytes));
-    c->ws = slot;
-    return HCTR_OK;
-}
-
-// scratch of the fused beam front end for the active workspace (first beam call on this shape)
-int ensure_beam_ws(hctr_ctx* c) {
-    if (c->ws.emit_list) return HCTR_OK;
-    if (c->ws_cache.empty() || c->ws_cache.front().B != c->ws.B || c->ws_cache.front().W != c->ws.W)
-        return fail(c, HCTR_ERR_STATE, "no active workspace");
-    Workspace& slot = c->ws_cache.front();
-    const size_t cols = (size_t)slot.B * slot.W, P = (size_t)c->cpad / 128;
-    int rc = HCTR_OK;
-    auto A = [&](auto** out, size_t count) {
-        if (rc == HCTR_OK) rc = dev_alloc(c, slot.allocs, out, count, false, &slot.bytes);
-    };
-    A(&slot.psum, P * cols);
-    A(&slot.blank_logit, cols);
-    A(&slot.row_thr, 2 * cols);
-    A(&slot.emit_cnt, cols);
-    A(&slot.esum, P * cols);
-    A(&slot.overflow, 1);
-    A(&slot.emit_list, cols * kBeamCap * 2);          // last: emit_list != NULL means the whole set exists
-    if (rc != HCTR_OK) slot.emit_list = nullptr;
-    c->ws = slot;
-    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -673,6 +647,16 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
 // ResNet.forward :115-153 and hctr_model.forward :171-176; np.argmax(preds, 2) utils/ctc_codec.py:75.
 enum HeadMode { HEAD_LOGITS = 0, HEAD_ARGMAX = 1, HEAD_BEAM = 2 };
 
+// optional workspace parts a forward in this head mode uses. Callers pass them to ensure_workspace BEFORE the input
+// is staged: carving a part may move the arena, which would lose an image already copied into it.
+int ws_need(const hctr_ctx* c, HeadMode mode) {
+    int need = 0;
+    if (mode == HEAD_LOGITS) need |= WS_LOGITS;
+    if (mode == HEAD_BEAM) need |= WS_BEAM;
+    if (!(c->fuse_stem && !c->split)) need |= WS_S0;
+    return need;
+}
+
 // the head projection's launch arguments for the active workspace (models/handwritten_ctr_model.py:175)
 void head_args(hctr_ctx* c, ConvArgs* out, ConvTile* tile) {
     const Workspace& ws = c->ws;
@@ -687,8 +671,8 @@ void head_args(hctr_ctx* c, ConvArgs* out, ConvTile* tile) {
 }
 
 int run_forward(hctr_ctx* c, int img_f32, bool have_widths, HeadMode mode = HEAD_LOGITS) {
-    if (mode == HEAD_LOGITS) TRY(ensure_logits(c));
-    if (mode == HEAD_BEAM) TRY(ensure_beam_ws(c));
+    if ((c->ws.features & ws_need(c, mode)) != ws_need(c, mode))
+        return fail(c, HCTR_ERR_STATE, "workspace lacks a part this forward needs (ensure_workspace before staging)");
     Workspace& ws = c->ws;
     Prof pf(c);
     if (c->fuse_stem && !c->split) {
@@ -696,7 +680,6 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths, HeadMode mode = HEAD
         TRY(run_conv(c, pf, "stem+conv0_2+pool", c->conv0_2, ActDesc{nullptr, 128, 64}, ws.x[1], 64, true, true, nullptr,
                      false, nullptr, nullptr, nullptr, nullptr, img_f32 ? 1 : 0, have_widths));
     } else {
-        TRY(ensure_s0(c));
         pf.begin("stem.conv0_1");
         HIP_TRY(c, launch_stem(ws.img, img_f32, have_widths ? ws.widths : nullptr, c->stem_w, c->stem_b, ws.s0, ws.B,
                                ws.W, ws.Wa, c->split, c->stream));
@@ -863,10 +846,6 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
         if (const char* fd = getenv("HCTR_FUSE_DS")) c->fuse_ds = atoi(fd) != 0;
         if (const char* fb = getenv("HCTR_FUSE_BEAM")) c->fuse_beam = atoi(fb) != 0;
         if (const char* fs2 = getenv("HCTR_FUSE_STEM")) c->fuse_stem = atoi(fs2) != 0;
-        if (const char* wb = getenv("HCTR_WS_BUDGET_GB")) {
-            const long long v = atoll(wb);
-            if (v > 0) c->ws_budget = (size_t)v << 30;
-        }
         if (const char* mc = getenv("HCTR_MAX_COLS")) {
             const long long v = atoll(mc);
             if (v > 0) c->max_cols = v;
@@ -880,7 +859,7 @@ void hctr_destroy(hctr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (auto& w : c->ws_cache) free_pool(w.allocs);
+    if (c->arena) (void)hipFree(c->arena);
     free_pool(c->wallocs);
     free_pool(c->beam_allocs);
     if (c->stamp_buf) (void)hipFree(c->stamp_buf);
@@ -1018,7 +997,7 @@ int hctr_forward_logits(hctr_ctx* c, const void* img, int img_dtype, int img_on_
         int rc = HCTR_OK;
         for (int b0 = 0; b0 < B && rc == HCTR_OK; b0 += nbmax) {
             const int nb = std::min(nbmax, B - b0);
-            rc = ensure_workspace(c, nb, W);
+            rc = ensure_workspace(c, nb, W, ws_need(c, HEAD_LOGITS));
             if (rc == HCTR_OK) rc = stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W);
             if (rc == HCTR_OK) rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr);
             if (rc == HCTR_OK) {
@@ -1052,7 +1031,7 @@ int hctr_greedy(hctr_ctx* c, const void* img, int img_dtype, int img_on_device, 
         // before returning, so nothing is in flight into (or out of) caller memory after an error
         int rc = HCTR_OK;
         auto pass = [&](int b0, int nb) -> int {
-            TRY(ensure_workspace(c, nb, W));
+            TRY(ensure_workspace(c, nb, W, ws_need(c, c->fuse_argmax ? HEAD_ARGMAX : HEAD_LOGITS)));
             TRY(stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W));
             TRY(run_forward(c, img_dtype == HCTR_F32, widths != nullptr, c->fuse_argmax ? HEAD_ARGMAX : HEAD_LOGITS));
             Workspace& ws = c->ws;
@@ -1160,7 +1139,7 @@ int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_d
             // more than kBeamCap list slots (near-uniform logits) is redone through the stored-logits kernels.
             bool fused = from_img && c->fuse_beam && k <= kBeamMaxK && k <= c->cpad / 128;
             if (from_img) {
-                rc = ensure_workspace(c, nb, W);
+                rc = ensure_workspace(c, nb, W, ws_need(c, fused ? HEAD_BEAM : HEAD_LOGITS));
                 if (rc == HCTR_OK) rc = stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W);
                 if (rc == HCTR_OK) rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr, fused ? HEAD_BEAM : HEAD_LOGITS);
                 rowsrc = c->ws.logits; ld = c->cpad;
@@ -1200,10 +1179,12 @@ int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_d
                     if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "beam overflow flag: %s", hipGetErrorString(e));
                 }
                 if (rc != HCTR_OK) break;
-                if (ovf) {                       // redo this pass with stored logits
+                if (ovf) {                       // redo this pass with stored logits (re-staged: carving may move the arena)
                     fused = false;
                     ++c->beam_fallbacks;
-                    rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr, HEAD_LOGITS);
+                    rc = ensure_workspace(c, nb, W, ws_need(c, HEAD_LOGITS));
+                    if (rc == HCTR_OK) rc = stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W);
+                    if (rc == HCTR_OK) rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr, HEAD_LOGITS);
                     if (rc != HCTR_OK) break;
                     rowsrc = c->ws.logits;
                 }

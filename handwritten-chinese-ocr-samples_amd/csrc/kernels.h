@@ -99,6 +99,10 @@ size_t conv_lds_bytes(ConvTile tile);
 // (2,1) max-pool from it: conv0_1's 16 kB-per-column output never exists in HBM (f16 mode; a.w/bias = conv0_2's)
 hipError_t launch_stem_conv0_2(const ConvArgs& a, hipStream_t s);
 
+// zero the stored conv border of a padded NHWC activation [B][H+2][Wa][C]: rows 0 and H+1, column 0 and columns
+// > W of every other row (the interior is rewritten by every forward; see engine.cpp ensure_workspace)
+hipError_t launch_zero_borders(half_t* p, int B, int H, int W, int Wa, int C, hipStream_t s);
+
 hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, const float* w9,
                        const float* bias, half_t* y, int B, int W, int Wa, int split, hipStream_t s);
 

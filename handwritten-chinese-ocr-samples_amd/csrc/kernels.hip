@@ -1382,6 +1382,28 @@ __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ img,
     }
 }
 
+// border rows / columns of a padded NHWC activation (one block per (row, image); 16-byte stores)
+__global__ __launch_bounds__(256) void zero_borders_kernel(half_t* __restrict__ p, int H, int W, int Wa, int C) {
+    const int row = blockIdx.x, b = blockIdx.y;
+    u32x4* r = (u32x4*)(p + ((int64_t)b * (H + 2) + row) * (int64_t)Wa * C);
+    const int vpp = C >> 3;                                 // 16-byte vectors per pixel
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    if (row == 0 || row == H + 1) {
+        for (int i = threadIdx.x; i < Wa * vpp; i += 256) r[i] = z;
+        return;
+    }
+    for (int i = threadIdx.x; i < vpp; i += 256) r[i] = z;                               // column 0
+    const int first = (W + 1) * vpp, n = (Wa - W - 1) * vpp;                              // columns W+1 .. Wa-1
+    for (int i = threadIdx.x; i < n; i += 256) r[first + i] = z;
+}
+
+hipError_t launch_zero_borders(half_t* p, int B, int H, int W, int Wa, int C, hipStream_t s) {
+    if (B == 0) return hipSuccess;
+    if (C % 8 != 0 || Wa < W + 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(zero_borders_kernel, dim3(H + 2, B), dim3(256), 0, s, p, H, W, Wa, C);
+    return hipGetLastError();
+}
+
 hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, const float* w9,
                        const float* bias, half_t* y, int B, int W, int Wa, int split, hipStream_t s) {
     if (B == 0) return hipSuccess;

@@ -965,3 +965,33 @@ def test_config5_beam_strings_equal_the_real_reference_end_to_end(pkg, synth):
             fe = m.beam_frontend(imgs, k=10, want_candidates=skip)
             assert cd.decode_frontend(fe) == gold[tag], (mode, tag)
         del cd, m
+
+
+def test_shape_changes_reuse_one_arena(pkg, synth, state_dict):
+    """Ragged workloads present a new (lines, width) with almost every batch. The workspace lives in ONE arena that is
+    re-carved per shape with only the stored conv borders re-zeroed: results must not depend on which shapes ran before
+    (stale interior / border data of a wider, narrower, larger or smaller previous shape), including when a later call
+    needs a part the layout did not have yet (logits for hctr_forward_logits, the beam scratch)."""
+    C = synth.DEFAULT_VOCAB + 2
+    shapes = [(3, 200), (2, 333), (5, 64), (1, 1000), (4, 97), (2, 32), (3, 200)]
+    imgs = {sh: synth.make_line_images(sh[0], sh[1], 70 + i) for i, sh in enumerate(shapes)}
+    want = {}
+    for sh in set(shapes):                                   # each shape on a fresh engine: nothing ran before
+        m = pkg.hctr_model(C).cuda(0)
+        m.load_state_dict(state_dict)
+        want[sh] = (m.greedy(imgs[sh]), m(imgs[sh]) if sh[1] <= 200 else None)
+        del m
+    m = pkg.hctr_model(C).cuda(0)
+    m.load_state_dict(state_dict)
+    for rnd in range(2):
+        for sh in shapes if rnd == 0 else shapes[::-1]:
+            got = m.greedy(imgs[sh])
+            assert all(np.array_equal(a, b) for a, b in zip(got, want[sh][0])), (rnd, sh)
+            if want[sh][1] is not None and rnd == 1:         # second round: the logits part joins the layout mid-way
+                assert np.array_equal(m(imgs[sh]), want[sh][1]), sh
+    fe = m.beam_frontend(imgs[(2, 32)], k=10)                # and the beam scratch
+    m2 = pkg.hctr_model(C).cuda(0)
+    m2.load_state_dict(state_dict)
+    fe2 = m2.beam_frontend(imgs[(2, 32)], k=10)
+    assert np.array_equal(fe["topk_idx"], fe2["topk_idx"]) and np.array_equal(fe["topk_logp"], fe2["topk_logp"])
+    assert all(np.array_equal(a, b) for a, b in zip(m.greedy(imgs[(1, 1000)]), want[(1, 1000)][0]))
