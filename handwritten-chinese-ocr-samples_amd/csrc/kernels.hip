@@ -46,6 +46,10 @@ __device__ __forceinline__ float dpp_f32(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
+// np.argmax order (utils/ctc_codec.py:75): a NaN counts as the maximum, the FIRST maximum wins
+__device__ __forceinline__ bool np_gt(float a, float b) { return a > b || (a != a && b == b); }
+__device__ __forceinline__ bool np_eq(float a, float b) { return a == b || (a != a && b != b); }
+
 // Same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (no 64-bit VALU address).
 __device__ __forceinline__ void glds16_asm_s(const char* sbase, uint32_t voff, char* lds_dst) {
     const uint32_t lds = (uint32_t)(uintptr_t)((lptr_t)lds_dst);
@@ -155,13 +159,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
                 for (int i = 0; i < 4; ++i) {
                     const int cls = cw0 + co(j) + i;
                     const float v = acc[j][n][i];
-                    if (cls < a.Cout && v > bv) { bv = v; bi = cls; }
+                    if (cls < a.Cout && np_gt(v, bv)) { bv = v; bi = cls; }
                 }
 #pragma unroll
             for (int off = 16; off <= 32; off <<= 1) {
                 const float ov = __shfl_xor(bv, off);
                 const int oi = __shfl_xor(bi, off);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                if (np_gt(ov, bv) || (np_eq(ov, bv) && oi < bi)) { bv = ov; bi = oi; }
             }
             const int64_t m = (int64_t)mt * BM + wm * 64 + n * 16 + c;
             if (q == 0 && m < a.M) {
@@ -1866,6 +1870,10 @@ hipError_t launch_se_apply(half_t* o, const half_t* r, const float* scale, int64
 // argmax_rows: np.argmax(preds, 2) (utils/ctc_codec.py:75): first maximum wins.
 // One wave per row; lanes read 16-byte vectors; tie-break on the lower index.
 // -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void argmax_merge_np(float& v, int& i, float ov, int oi) {
+    if (np_gt(ov, v) || (np_eq(ov, v) && oi < i)) { v = ov; i = oi; }
+}
+
 __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi) {
     if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
@@ -1883,17 +1891,17 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
         const f32x4 v = *(const f32x4*)(p + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (v[e] > bv) { bv = v[e]; bi = c + e; }
+            if (np_gt(v[e], bv)) { bv = v[e]; bi = c + e; }
     }
     for (int c = c4 + lane; c < C; c += 64) {
         const float v = p[c];
-        if (v > bv) { bv = v; bi = c; }
+        if (np_gt(v, bv)) { bv = v; bi = c; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float ov = __shfl_xor(bv, off);
         const int oi = __shfl_xor(bi, off);
-        argmax_merge(bv, bi, ov, oi);
+        argmax_merge_np(bv, bi, ov, oi);
     }
     if (lane == 0) {
         // tB > 0: input rows are r = t*tB + b (WBC order), output is [b][t]
@@ -1912,7 +1920,7 @@ __global__ __launch_bounds__(256) void argmax_partials_kernel(const float* __res
     for (int p = 0; p < P; ++p) {
         const float v = val[(int64_t)p * M + m];
         const int i = cls[(int64_t)p * M + m];
-        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        if (np_gt(v, bv) || (np_eq(v, bv) && i < bi)) { bv = v; bi = i; }
     }
     idx[m] = (bi == 0x7fffffff) ? 0 : bi;
 }

@@ -995,3 +995,27 @@ def test_shape_changes_reuse_one_arena(pkg, synth, state_dict):
     fe2 = m2.beam_frontend(imgs[(2, 32)], k=10)
     assert np.array_equal(fe["topk_idx"], fe2["topk_idx"]) and np.array_equal(fe["topk_logp"], fe2["topk_logp"])
     assert all(np.array_equal(a, b) for a, b in zip(m.greedy(imgs[(1, 1000)]), want[(1, 1000)][0]))
+
+
+def test_nan_logits_follow_numpy_argmax(pkg, engine, synth, state_dict):
+    """np.argmax (utils/ctc_codec.py:75) treats a NaN as the maximum and returns the FIRST one; the device argmax
+    kernels - over caller-supplied logits and fused into the head GEMM - do the same."""
+    rng = np.random.default_rng(12)
+    C = 9
+    logits = rng.normal(size=(14, 2, C)).astype(np.float32)
+    logits[3, 0, 4] = np.nan
+    logits[3, 0, 6] = np.nan                    # two NaNs in a row: the first wins
+    logits[7, 1, 0] = np.nan                    # NaN on the blank
+    logits[9, 0, :] = -np.inf                   # all -inf: index 0
+    logits[10, 1, 2] = np.inf
+    cd = pkg.ctc_codec(codec_cases.vocab(C)).attach(engine)
+    assert cd.decode(logits) == ctc_ref.CtcCodecRef(codec_cases.vocab(C)).decode(logits)
+    sd = dict(state_dict)
+    bias = state_dict["linear.bias"].copy()
+    bias[5] = np.nan                            # every column's logit of class 5 is NaN
+    sd["linear.bias"] = bias
+    m = pkg.hctr_model(synth.DEFAULT_VOCAB + 2).cuda(0)
+    m.load_state_dict(sd)
+    imgs = synth.make_line_images(2, 80, 4)
+    assert [lab.tolist() for lab in m.greedy(imgs)] == [[5], [5]]
+    assert (np.nanargmax(np.where(np.isnan(m(imgs)), np.inf, m(imgs)), axis=2) == 5).all()

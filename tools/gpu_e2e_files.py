@@ -1,6 +1,7 @@
 """End-to-end files -> text throughput of the drop-in CLI on the GPU box (host decode + device resize + forward +
-greedy decode + CER bookkeeping):  python tools/gpu_e2e_files.py [n_files] [batch] [workers]
-Writes n synthetic half-height PNG line images (64 x 1000 -> resized on the device to 128 x 2000) and a
+greedy decode + CER bookkeeping):  python tools/gpu_e2e_files.py [n_files] [batch] [workers] [ragged]
+Writes n synthetic half-height PNG line images (64 x 1000 -> resized on the device to 128 x 2000; with "ragged" the
+source widths vary between 400 and 800, so that every batch pads to a different width <= 1600) and a
 test_img_id_gt.txt into a temporary folder, runs `test.py -bm` on it and reports lines/s from its own clock."""
 import os
 import re
@@ -19,13 +20,17 @@ from PIL import Image  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 workers = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+ragged = len(sys.argv) > 4 and sys.argv[4] == "ragged"
 synth = hctr_amd.synth
 with tempfile.TemporaryDirectory() as d:
     os.makedirs(os.path.join(d, "test"))
     imgs = synth.make_line_images(n, 2000, seed=77)
     with open(os.path.join(d, "test_img_id_gt.txt"), "w", encoding="utf-8") as f:
         for i in range(n):
-            Image.fromarray(imgs[i][::2, ::2]).save(os.path.join(d, "test", "%06d.png" % i))
+            half = imgs[i][::2, ::2]
+            if ragged:
+                half = half[:, :400 + int(synth.uniform01(77, 5, 1, offset=i)[0] * 400)]
+            Image.fromarray(half).save(os.path.join(d, "test", "%06d.png" % i))
             f.write("%06d.png,%s\n" % (i, synth.characters()[i % 100]))
     for w in (0, workers):
         t0 = time.time()
