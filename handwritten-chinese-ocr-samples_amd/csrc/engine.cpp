@@ -80,6 +80,7 @@ struct Workspace {
     int32_t* emit_list = nullptr;   // [B*W][kBeamCap][2]
     double* esum = nullptr;         // [P][B*W]
     int32_t* overflow = nullptr;    // [1]
+    int32_t* tile_ctrs = nullptr;   // [64 launches][8 XCDs] tile queues of the persistent conv variant (HCTR_PERSIST=2)
     int features = 0;               // WS_* sets carved into this layout
 };
 
@@ -131,6 +132,8 @@ struct hctr_ctx {
     int64_t stamp_cap = 0, stamp_n = 0;
     bool fuse_ds = true;             // 1x1 downsample inside conv2's K loop (HCTR_FUSE_DS=0: own launch + residual)
     bool fuse_argmax = true;         // greedy: argmax in the head GEMM's epilogue (HCTR_FUSE_ARGMAX=0: separate pass)
+    bool persist_dynamic = false;    // HCTR_PERSIST=2: persistent conv workgroups drawing tiles from an atomic queue
+    int conv_seq = 0;                // conv launches of the current forward (one queue each)
     bool fuse_stem = true;           // conv0_1 inside conv0_2's loader (HCTR_FUSE_STEM=0: own launch + 16 kB/column buffer)
     bool fuse_beam = true;           // beam front end without stored logits (HCTR_FUSE_BEAM=0: logits + row_topk)
     int64_t beam_fallbacks = 0;      // passes that overflowed a row list and were redone through the logits
@@ -425,6 +428,7 @@ int ensure_workspace(hctr_ctx* c, int B, int W, int features = 0) {
     A(&ws.amax_idx, cols * (c->cpad / 64));
     A(&ws.labels, cols);
     A(&ws.lengths, (size_t)B);
+    A(&ws.tile_ctrs, (size_t)64 * 8);
     // conv0_1's output (16 kB per column): only the unfused / f16x3 stem path
     if (feat & WS_S0) A(&ws.s0, (size_t)act_elems(B, 128, Wa, 64 * m));
     // [B*W][cpad] fp32 logits (3.8 GB at config 2): hctr_forward_logits and the HCTR_FUSE_* = 0 A/B paths only
@@ -569,6 +573,7 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
     }
     a.mtiles = ws.B * a.tilesH * a.tilesW;
     a.ntiles = cw.coutPad / conv_tile_couts(tile);
+    if (c->persist_dynamic && c->conv_seq < 64) a.tile_counter = ws.tile_ctrs + 8 * c->conv_seq++;
     if (c->stamp_buf && c->stamp_layer == name && (tile == TILE_HALO4 || tile == TILE_HALO4_8x32) &&
         (int64_t)a.mtiles * a.ntiles <= c->stamp_cap) {
         a.stamps = c->stamp_buf;
@@ -675,6 +680,10 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths, HeadMode mode = HEAD
         return fail(c, HCTR_ERR_STATE, "workspace lacks a part this forward needs (ensure_workspace before staging)");
     Workspace& ws = c->ws;
     Prof pf(c);
+    if (c->persist_dynamic) {
+        HIP_TRY(c, hipMemsetAsync(ws.tile_ctrs, 0, 64 * 8 * 4, c->stream));
+        c->conv_seq = 0;
+    }
     if (c->fuse_stem && !c->split) {
         // conv0_1's output (16 kB per pixel column) never reaches HBM: it is computed into conv0_2's LDS halo
         TRY(run_conv(c, pf, "stem+conv0_2+pool", c->conv0_2, ActDesc{nullptr, 128, 64}, ws.x[1], 64, true, true, nullptr,
@@ -846,6 +855,7 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
         if (const char* fd = getenv("HCTR_FUSE_DS")) c->fuse_ds = atoi(fd) != 0;
         if (const char* fb = getenv("HCTR_FUSE_BEAM")) c->fuse_beam = atoi(fb) != 0;
         if (const char* fs2 = getenv("HCTR_FUSE_STEM")) c->fuse_stem = atoi(fs2) != 0;
+        if (const char* ps = getenv("HCTR_PERSIST")) c->persist_dynamic = atoi(ps) == 2;
         if (const char* mc = getenv("HCTR_MAX_COLS")) {
             const long long v = atoll(mc);
             if (v > 0) c->max_cols = v;

@@ -72,6 +72,7 @@ struct ConvArgs {
     int ds_cin;
     int ds_in_sh;             // elements per image row of ds_x
     int64_t ds_in_sb;         // elements per image of ds_x
+    int32_t* tile_counter;        // persistent halo4 variant with a dynamic tile queue: 8 ints (one per XCD), zero at launch
     unsigned long long* stamps;   // diagnostic instance only (hctr_debug_stamps): 16 x u64 per workgroup, else NULL
     // timing experiments only (HCTR_DBG), results INVALID. 8-wave/generic kernels: 1 = DMA from fixed hot addresses,
     // 2 = no DMA in the loop. halo4 kernel, bit mask: 32 = no halo reload at chunk boundaries, 64 = no K loop,

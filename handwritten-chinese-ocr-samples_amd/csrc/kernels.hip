@@ -926,6 +926,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     };
     int tidx = local;
     if (tidx >= xcnt) return;                       // (persistent grids may exceed a short XCD run)
+    // Persistent variant, DYNAMIC tile queue (a.tile_counter set): the first two tiles of a workgroup are the static
+    // ones (local, local + nloc); every later tile index is drawn from the XCD's atomic counter one tile ahead, so the
+    // draw's latency hides behind a whole K loop and the hardware dispatcher's balancing is kept.
+    const bool dynamic = PERSIST && a.tile_counter != nullptr;
+    int tnext = local + nloc;
+    volatile int* lds_next = (volatile int*)(smem + kHalo4Lds + 4 * 128 * 4);       // two words behind the epilogue scratch
 
     const int wrow = GEOM ? (wm >> 1) * 4 : wm * 4;               // this wave's 4 x 16 patch inside the tile
     const int wcol = GEOM ? (wm & 1) * 16 : 0;
@@ -984,15 +990,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     int kbase = 0;                                  // weight-buffer parity continues across tiles / phases
     bool first = true;
 
+    int tile_no = 0;
     for (;;) {
-        const bool has_next = PERSIST && (tidx + nloc < xcnt);
+        const bool has_next = PERSIST && (tnext < xcnt);
         const char* nxb = cur.xb;
         const char* nwb = cur.wb;
         if (has_next) {
-            const Tile t = tile_at(tidx + nloc);
+            const Tile t = tile_at(tnext);
             nxb = t.xb;
             nwb = t.wb;
         }
+        int drawn = 0;
+        if (dynamic && tid == 0)                        // index of the tile after next (used one tile from now)
+            drawn = 2 * nloc + __hip_atomic_fetch_add(a.tile_counter + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         f32x4 acc[JT][4];
         // One K step: 64 MFMAs of this wave on the weight tile at `wt` and the pixel fragments at be / bo.
         // Rolling fragment pipeline: 8 groups of 8 MFMAs (2 A fragments x 4 B fragments); A pairs are read two
@@ -1172,7 +1182,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         }
         if (!has_next) break;
         kbase += nk;
-        tidx += nloc;
+        tidx = tnext;
+        if (dynamic) {                                  // broadcast the drawn index (word alternates per tile: no WAR)
+            if (tid == 0) lds_next[tile_no & 1] = drawn;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+            tnext = __builtin_amdgcn_readfirstlane(lds_next[tile_no & 1]);
+        } else {
+            tnext = tidx + nloc;
+        }
+        ++tile_no;
         cur = tile_at(tidx);
     }
     if (a.dbg & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (K loop skipped: the prologue DMA is still in flight)
@@ -1190,7 +1209,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
 #ifndef LDS_PAD
 #define LDS_PAD 0      // A/B build switch: extra LDS bytes per workgroup (e.g. 40000 forces ONE workgroup per CU)
 #endif
-constexpr int kHalo4LdsTotal = kHalo4Lds + 4 * 128 * 4 + LDS_PAD;   // + [WM][BN] floats of epilogue scratch
+constexpr int kHalo4LdsTotal = kHalo4Lds + 4 * 128 * 4 + 16 + LDS_PAD;   // + [WM][BN] floats of epilogue scratch + 2 queue words
 
 template <int GEOM, bool SPLIT, bool PERSIST>
 static hipError_t launch_conv_halo4_tp(const ConvArgs& a0, hipStream_t s) {
@@ -1239,9 +1258,13 @@ static hipError_t launch_conv_halo4_t(const ConvArgs& a, hipStream_t s) {
                            kHalo4LdsTotal, s, a);
         return hipGetLastError();
     }
-    // persistent tiles measured 6-8 % SLOWER on every layer (r01): kept for A/B only
-    static const bool persist = [] { const char* e = getenv("HCTR_PERSIST"); return e ? atoi(e) != 0 : false; }();
-    return persist ? launch_conv_halo4_tp<GEOM, SPLIT, true>(a, s) : launch_conv_halo4_tp<GEOM, SPLIT, false>(a, s);
+    // persistent tiles with a STATIC stride measured 6-8 % slower on every layer (r01); HCTR_PERSIST=2 draws tiles
+    // from an atomic queue instead (a.tile_counter, zeroed by the engine once per forward)
+    static const int persist = [] { const char* e = getenv("HCTR_PERSIST"); return e ? atoi(e) : 0; }();
+    if (persist == 0 || (persist == 2 && a.tile_counter == nullptr)) return launch_conv_halo4_tp<GEOM, SPLIT, false>(a, s);
+    ConvArgs b = a;
+    if (persist != 2) b.tile_counter = nullptr;
+    return launch_conv_halo4_tp<GEOM, SPLIT, true>(b, s);
 }
 template <int GEOM>
 static hipError_t launch_conv_halo4(const ConvArgs& a, hipStream_t s) {
