@@ -1489,6 +1489,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv0_2_kernel(const ConvArgs a) 
         }
     };
     stage_w(0, 0);
+    stage_w(1, 1);                                   // both buffers are free here: two steps' weights fly during the conv0_1 phase
 
     // ---- 20 x 20 patch of the normalised image (zero outside the image: conv0_1's padding; columns >= the line's
     //      width replicate its last column: NormalizePAD) ----
@@ -1515,11 +1516,18 @@ __global__ __launch_bounds__(256, 2) void stem_conv0_2_kernel(const ConvArgs a) 
     // conv0_1 weights of this thread's 8-channel group
     const int cg = tid & 7;
     float wt[8][9], bs[8];
+    {
+        const f32x4* wp = (const f32x4*)(a.stem_w + cg * 72);
+        const f32x4* bp = (const f32x4*)(a.stem_b + cg * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        bs[e] = a.stem_b[cg * 8 + e];
+        for (int v = 0; v < 18; ++v) {
+            const f32x4 w4 = wp[v];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wt[e][t] = a.stem_w[(cg * 8 + e) * 9 + t];
+            for (int i = 0; i < 4; ++i) wt[(v * 4 + i) / 9][(v * 4 + i) % 9] = w4[i];
+        }
+        const f32x4 b0 = bp[0], b1 = bp[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { bs[i] = b0[i]; bs[4 + i] = b1[i]; }
     }
     __syncthreads();
     // ---- conv0_1 + bn0_1 + ReLU into the halo: unit = (halo pixel, 8 channels) -> one 16-byte LDS store ----
@@ -1559,7 +1567,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv0_2_kernel(const ConvArgs a) 
     for (int st = 0; st < 5; ++st) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's weight pieces of step st have landed
         __syncthreads();                                               // ... everyone's, and (st == 0) the halo is written
-        if (st + 1 < 5) stage_w(st + 1, (st + 1) & 1);
+        if (st >= 1 && st + 1 < 5) stage_w(st + 1, (st + 1) & 1);      // (step 1's weights were issued up front)
         const int ntap = st == 4 ? 1 : 2;
         for (int tt = 0; tt < ntap; ++tt) {
             const int tap = st * 2 + tt;
