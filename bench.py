@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--checkpoint", default="random", choices=["random", "trained"],
                     help="synthetic checkpoint: near-tie-rich random head (default) or the trained-like head")
     ap.add_argument("--no-pipeline", action="store_true", help="c5: run front end and host search back to back")
+    ap.add_argument("--chunk", type=int, default=64, help="c5: lines per pipeline chunk")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"],
                     help="c2 (default, the driver's line): B=64 x W=2000 greedy at 1 GPU, configs[3] (B=4096 sharded) "
                          "at N > 1; c3: B=512 mixed widths {800,1600,2400,3200} bucketed; c5: B=256 x W=2000 beam "
@@ -413,7 +414,7 @@ def extra_config(args, hctr_amd, model, sd, dev):
                 fe = model.beam_frontend(dev_imgs, k=10)
                 t_front[0] += time.perf_counter() - t0
                 return codec.decode_frontend(fe)
-            return pipe.recognize_beam(model, codec, dev_imgs, chunk=64)
+            return pipe.recognize_beam(model, codec, dev_imgs, chunk=args.chunk)
         n_lines, cols = 256, 256 * W_LINE
         name = ("BASELINE configs[4]: B=256 x 1x128x2000, cbs_full beam 10 / depth 10, toy-bigram LM, "
                 "device log-softmax+top-k, C++ host prefix search on %d threads, %s" %

@@ -96,7 +96,7 @@ class hctr_model(object):
         for k, v in state_dict.items():
             if _is_torch(v):
                 v = v.detach().cpu().numpy()
-            sd[k] = np.ascontiguousarray(v)
+            sd[k] = np.ascontiguousarray(v).reshape(np.shape(v))     # (ascontiguousarray makes 0-d entries 1-d)
         if self._ctx is None:
             self._pending_sd = sd          # uploaded when .cuda() binds a device
         else:
@@ -124,7 +124,17 @@ class hctr_model(object):
         self._sd_host = sd
 
     def state_dict(self):
-        raise NotImplementedError("weights live in kernel layouts on the device; keep the checkpoint dict")
+        """The checkpoint dict this model was loaded from (reference key schema, ``main.py:349-356``), as torch CPU
+        tensors when torch is importable, else numpy arrays. The device copy lives in kernel layouts (BatchNorm folded,
+        fp16 MFMA row order) and is not read back."""
+        if self._sd_host is None and self._pending_sd is None:
+            raise RuntimeError("hctr_model has no weights: call load_state_dict(...) first")
+        sd = self._sd_host if self._sd_host is not None else self._pending_sd
+        try:
+            import torch
+            return collections.OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in sd.items())
+        except ImportError:
+            return collections.OrderedDict((k, np.array(v)) for k, v in sd.items())
 
     def _release(self):
         if self._ctx is not None:

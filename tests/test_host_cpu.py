@@ -397,3 +397,22 @@ def test_abi_no_exception_crosses():
     assert run(4, 8)[0] == -7              # no room for a thread stack either: falls back to the caller's thread
     rc, total = run(4096, 8)
     assert rc == 0 and total > 0
+
+
+def test_state_dict_round_trip_without_gpu(pkg, synth):
+    """``model.state_dict()`` hands back the loaded checkpoint in the reference's key schema (254 entries,
+    main.py:349-356), so a caller can save / reload it like the reference's nn.Module (no GPU needed: the weights wait
+    for ``.cuda()``)."""
+    import torch
+    C = 40
+    sd = synth.make_state_dict(C, seed=3, calib=None)
+    m = pkg.hctr_model(C)
+    with pytest.raises(RuntimeError):
+        m.state_dict()
+    m.load_state_dict(sd)
+    back = m.state_dict()
+    assert list(back.keys()) == list(sd.keys()) and len(back) == 254
+    assert all(isinstance(v, torch.Tensor) and np.array_equal(v.numpy(), sd[k]) for k, v in back.items())
+    m2 = pkg.hctr_model(C)
+    m2.load_state_dict(back)                               # torch tensors are accepted like numpy arrays
+    assert np.array_equal(m2.state_dict()["linear.weight"].numpy(), sd["linear.weight"])
