@@ -49,13 +49,61 @@ struct Node {
     uint32_t cp;        // toy LM: code point of `label` (0 at the root); n-gram LM: its word id
 };
 
+// (parent node, label) -> child node: open addressing in one flat array. The search of a 2000-column line creates
+// ~200 000 nodes; a node-based std::unordered_map made one allocation per insert, and 64 lines decoding at once spent
+// their time in the allocator and in page faults (80 -> 270 ms per 64-line chunk from run to run). The table is
+// reused from line to line by its worker thread (reset keeps the capacity).
+struct KidMap {
+    static constexpr uint64_t kEmpty = ~0ull;              // (node < 2^31, so no key is all ones)
+    std::vector<uint64_t> keys;
+    std::vector<int> vals;
+    size_t mask = 0, count = 0;
+    static size_t mix(uint64_t k) {
+        k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+        return (size_t)k;
+    }
+    void reset() {
+        if (keys.empty()) { keys.assign(1 << 12, kEmpty); vals.assign(1 << 12, 0); }
+        else std::fill(keys.begin(), keys.end(), kEmpty);
+        mask = keys.size() - 1;
+        count = 0;
+    }
+    int find(uint64_t key) const {
+        for (size_t i = mix(key) & mask;; i = (i + 1) & mask) {
+            if (keys[i] == key) return vals[i];
+            if (keys[i] == kEmpty) return -1;
+        }
+    }
+    void insert(uint64_t key, int val) {                   // key must be absent
+        if ((count + 1) * 2 > keys.size()) {
+            std::vector<uint64_t> ok(keys.size() * 2, kEmpty);
+            std::vector<int> ov(keys.size() * 2, 0);
+            ok.swap(keys); ov.swap(vals);
+            mask = keys.size() - 1;
+            for (size_t j = 0; j < ok.size(); ++j)
+                if (ok[j] != kEmpty) {
+                    size_t i = mix(ok[j]) & mask;
+                    while (keys[i] != kEmpty) i = (i + 1) & mask;
+                    keys[i] = ok[j]; vals[i] = ov[j];
+                }
+        }
+        size_t i = mix(key) & mask;
+        while (keys[i] != kEmpty) i = (i + 1) & mask;
+        keys[i] = key; vals[i] = val;
+        ++count;
+    }
+};
+
 struct Trie {
     std::vector<Node> nodes;
-    std::unordered_map<uint64_t, int> kids;
-    const int32_t* cps;
+    KidMap kids;
+    const int32_t* cps = nullptr;
     const hctr_ngram* lm = nullptr;       // built-in ARPA LM (cps then maps label -> word id)
-    explicit Trie(const int32_t* codepoints, const hctr_ngram* ngram = nullptr) : cps(codepoints), lm(ngram) {
+    void reset(const int32_t* codepoints, const hctr_ngram* ngram = nullptr) {
+        cps = codepoints; lm = ngram;
+        nodes.clear();
         nodes.push_back(Node{-1, -1, 0, 0.0, 0u});
+        kids.reset();
     }
     // the last (order-1) word ids of prefix(node), oldest first, preceded by <s> when the prefix is short
     int lm_context(int node, int32_t* ctx) const {
@@ -77,8 +125,8 @@ struct Trie {
     }
     int child(int node, int32_t label) {
         const uint64_t key = ((uint64_t)(uint32_t)node << 32) | (uint32_t)label;
-        auto it = kids.find(key);
-        if (it != kids.end()) return it->second;
+        const int hit = kids.find(key);
+        if (hit >= 0) return hit;
         const Node p = nodes[node];
         const uint32_t cp = cps ? (uint32_t)cps[label] : 0u;
         double sc = 0.0;
@@ -90,7 +138,7 @@ struct Trie {
             sc = p.toy + toy_term(p.cp, cp);
         }
         nodes.push_back(Node{node, label, p.len + 1, sc, cp});
-        kids.emplace(key, (int)nodes.size() - 1);
+        kids.insert(key, (int)nodes.size() - 1);
         return (int)nodes.size() - 1;
     }
     void append_labels(int node, std::vector<int32_t>& out) const {      // root -> node order
@@ -250,12 +298,24 @@ int beam_step(const hctr_beam_params& P, const LineInput& in, int t, Trie& trie,
     return HCTR_OK;
 }
 
-int decode_line(const hctr_beam_params& P, const LineInput& in, int32_t* out_labels, int32_t* out_len) {
+// everything a line's search allocates, owned by a worker thread and reused from line to line (capacities are kept;
+// Scratch's epoch keeps counting, so stamps left by an earlier line never match)
+struct LineWork {
+    Trie trie;
+    Scratch S;
+    std::vector<Hyp> beams;
+    std::vector<int32_t> suffix, line_lab, line_t, best;
+};
+
+int decode_line(const hctr_beam_params& P, const LineInput& in, int32_t* out_labels, int32_t* out_len, LineWork& wk) {
     const int W = in.W, B = in.B, C = in.C, k = in.k, b = in.b;
     const int unk = C - 1;
     *out_len = 0;
     // greedy pass with time stamps (:133-140, :188-195)
-    std::vector<int32_t> line_lab, line_t;
+    std::vector<int32_t>& line_lab = wk.line_lab;
+    std::vector<int32_t>& line_t = wk.line_t;
+    line_lab.clear();
+    line_t.clear();
     int prev = -1;
     for (int t = 0; t < W; ++t) {
         const int c1 = in.topk_idx[((size_t)t * B + b) * k];
@@ -265,11 +325,13 @@ int decode_line(const hctr_beam_params& P, const LineInput& in, int32_t* out_lab
     if (line_lab.empty()) return HCTR_ERR_EMPTY_LINE;              // top_line[-1] -> IndexError (:143,198)
     int end_step = line_t.back() + 4;
     if (end_step >= W) end_step = W;
-    Trie trie(P.builtin_lm == 2 ? P.label_codepoints : (P.builtin_lm == 3 ? P.label_words : nullptr),
-              P.builtin_lm == 3 ? P.ngram : nullptr);
-    Scratch S;
-    std::vector<Hyp> beams(1, fresh_hyp());
-    std::vector<int32_t> suffix;
+    Trie& trie = wk.trie;
+    trie.reset(P.builtin_lm == 2 ? P.label_codepoints : (P.builtin_lm == 3 ? P.label_words : nullptr),
+               P.builtin_lm == 3 ? P.ngram : nullptr);
+    Scratch& S = wk.S;
+    std::vector<Hyp>& beams = wk.beams;
+    beams.assign(1, fresh_hyp());
+    std::vector<int32_t>& suffix = wk.suffix;
     size_t first_after = 0;                                         // first greedy entry with ts > t
     const int depth = std::min(P.search_depth, k);
     for (int t = 0; t < end_step; ++t) {
@@ -317,7 +379,8 @@ int decode_line(const hctr_beam_params& P, const LineInput& in, int32_t* out_lab
         }
     }
     if (beams.empty()) return HCTR_ERR_EMPTY_LINE;                  // kept_beams[0] -> IndexError (:179,208)
-    std::vector<int32_t> best;
+    std::vector<int32_t>& best = wk.best;
+    best.clear();
     trie.append_labels(beams[0].node, best);
     *out_len = (int32_t)best.size();
     if (!best.empty()) memcpy(out_labels, best.data(), best.size() * sizeof(int32_t));
@@ -350,13 +413,15 @@ extern "C" int hctr_beam_search(const hctr_beam_params* p, int W, int B, int C, 
     std::atomic<int> next(0);
     std::atomic<int> fault(HCTR_OK);
     auto worker = [&]() noexcept {
+        LineWork* wk = nullptr;
+        try { wk = new LineWork(); } catch (...) { fault.store(HCTR_ERR_NOMEM); next.store(B); return; }
         for (;;) {
             const int b = next.fetch_add(1);
             if (b >= B) break;
             int st;
             try {
                 LineInput in{W, B, C, k, b, topk_idx, topk_logp, blank_logp, cand_off, cand_idx, cand_logp, full_logp_wbc};
-                st = decode_line(*p, in, out_labels + (size_t)b * W, out_lengths + b);
+                st = decode_line(*p, in, out_labels + (size_t)b * W, out_lengths + b, *wk);
             } catch (const std::bad_alloc&) {
                 st = HCTR_ERR_NOMEM;
             } catch (...) {
@@ -368,6 +433,7 @@ extern "C" int hctr_beam_search(const hctr_beam_params* p, int W, int B, int C, 
                 next.store(B);
             }
         }
+        delete wk;
     };
     if (nthreads == 1) {
         worker();
