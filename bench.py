@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--checkpoint", default="random", choices=["random", "trained"],
                     help="synthetic checkpoint: near-tie-rich random head (default) or the trained-like head")
     ap.add_argument("--no-pipeline", action="store_true", help="c5: run front end and host search back to back")
-    ap.add_argument("--chunk", type=int, default=64, help="c5: lines per pipeline chunk")
+    ap.add_argument("--chunk", type=int, default=32, help="c5: lines per pipeline chunk")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"],
                     help="c2 (default, the driver's line): B=64 x W=2000 greedy at 1 GPU, configs[3] (B=4096 sharded) "
                          "at N > 1; c3: B=512 mixed widths {800,1600,2400,3200} bucketed; c5: B=256 x W=2000 beam "

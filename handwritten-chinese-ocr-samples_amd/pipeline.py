@@ -6,7 +6,7 @@ import queue
 import threading
 
 
-def recognize_beam(model, codec, images, widths=None, chunk=64):
+def recognize_beam(model, codec, images, widths=None, chunk=32):
     """Beam-decode ``images`` (uint8 [B,128,W] numpy array or torch tensor, optionally per-line widths)
     with ``codec``'s beam settings. Returns the decoded strings in input order. Every chunk is padded /
     processed exactly like a batch of its own (same results as calling the two stages back to back)."""
