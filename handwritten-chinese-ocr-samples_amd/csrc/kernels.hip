@@ -1650,11 +1650,35 @@ __global__ __launch_bounds__(256) void se_border_kernel(const half_t* __restrict
     const int per = (count + kBorderSeg - 1) / kBorderSeg;
     const int pbeg = seg * per, pend = pbeg + per < count ? pbeg + per : count;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (threadIdx.x < lanes * cv)
-        for (int p = pbeg + p0; p < pend; p += lanes) {
+    if (threadIdx.x < lanes * cv) {
+        auto addr = [&](int p) {
             const int h = job == 0 ? 0 : (job == 1 ? H - 1 : p);
             const int w = job == 2 ? 0 : (job == 3 ? W - 1 : p);
-            const half_t* px = img + ((int64_t)(h + 1) * Wa + (w + 1)) * cs + v * 8;
+            return img + ((int64_t)(h + 1) * Wa + (w + 1)) * cs + v * 8;
+        };
+        // four pixels' loads in flight at a time (the kernel is a chain of L2 round trips otherwise); the additions
+        // keep their order, so the sums are bit-identical to the one-at-a-time loop
+        int p = pbeg + p0;
+        for (; p + 3 * lanes < pend; p += 4 * lanes) {
+            f16x8 x[4], xl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const half_t* px = addr(p + u * lanes);
+                x[u] = *(const f16x8*)px;
+                if (split) xl[u] = *(const f16x8*)(px + C);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)x[u][e];
+                if (split) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += (float)xl[u][e];
+                }
+            }
+        }
+        for (; p < pend; p += lanes) {
+            const half_t* px = addr(p);
             const f16x8 x = *(const f16x8*)px;
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += (float)x[e];
@@ -1664,6 +1688,7 @@ __global__ __launch_bounds__(256) void se_border_kernel(const half_t* __restrict
                 for (int e = 0; e < 8; ++e) acc[e] += (float)xl[e];
             }
         }
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[e];
     __syncthreads();
@@ -1739,17 +1764,44 @@ __global__ __launch_bounds__(256) void se_premean_kernel(const float* __restrict
     const int srow = jj * 16 + qq * 4 + ii;
     float acc = 0.f;
     const int kper = 9 * C / 4;                        // this slice's share of the 9*C reduction
-    for (int kk = slice * kper; kk < (slice + 1) * kper; kk += 8) {
+    // eight 16-byte weight loads in flight per round (one dependent L2 round trip per 8 values otherwise); the FMAs
+    // keep their order, so the mean is bit-identical to the one-vector-at-a-time loop
+    int kk0 = slice * kper;
+    const int kend = (slice + 1) * kper;
+    for (; kk0 + 64 <= kend; kk0 += 64) {
+        f16x8 wv8[8], wl8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = kk0 + u * 8;
+            const int tap = kk / C, ci = kk - tap * C;
+            const half_t* wr = w + ((int64_t)tap * CoutPad + cg * 64 + srow) * cs + ci;
+            wv8[u] = *(const f16x8*)wr;
+            if (split) wl8[u] = *(const f16x8*)(wr + 2 * C);       // weight rows are [w_hi | w_hi | w_lo]
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = kk0 + u * 8;
+            const int tap = kk / C, ci = kk - tap * C;
+            if (split) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = fmaf((float)wv8[u][e] + (float)wl8[u][e], S[tap * C + ci + e], acc);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = fmaf((float)wv8[u][e], S[tap * C + ci + e], acc);
+            }
+        }
+    }
+    for (int kk = kk0; kk < kend; kk += 8) {           // tail (C = 128: 288 = 4 x 64 + 32 values per slice)
         const int tap = kk / C, ci = kk - tap * C;
         const half_t* wr = w + ((int64_t)tap * CoutPad + cg * 64 + srow) * cs + ci;
-        const f16x8 wv8 = *(const f16x8*)wr;
-        if (split) {                                   // weight rows are [w_hi | w_hi | w_lo]
-            const f16x8 wl8 = *(const f16x8*)(wr + 2 * C);
+        const f16x8 wv = *(const f16x8*)wr;
+        if (split) {
+            const f16x8 wl = *(const f16x8*)(wr + 2 * C);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc = fmaf((float)wv8[e] + (float)wl8[e], S[tap * C + ci + e], acc);
+            for (int e = 0; e < 8; ++e) acc = fmaf((float)wv[e] + (float)wl[e], S[tap * C + ci + e], acc);
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc = fmaf((float)wv8[e], S[tap * C + ci + e], acc);
+            for (int e = 0; e < 8; ++e) acc = fmaf((float)wv[e], S[tap * C + ci + e], acc);
         }
     }
     part[threadIdx.x] = acc;
