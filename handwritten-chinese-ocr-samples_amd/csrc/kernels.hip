@@ -12,6 +12,10 @@
 #ifndef BHALF_AT
 #define BHALF_AT 1     // MFMA group before which the second half of the B fragments is read
 #endif
+#ifndef DMA_SPREAD
+#define DMA_SPREAD 0   // A/B build switch: 0 = a step's 4 weight-DMA pieces right after the first fragment reads; 1 = one piece
+                       // after each of MFMA groups 0..3; 2 = after groups 0, 2, 4, 6 (issue cost in the MFMAs' shadow)
+#endif
 #ifndef NOPRIO
 #define NOPRIO 0       // A/B build switch (tools/ab_build.sh): 1 drops the s_setprio around MFMA groups
 #endif
@@ -947,6 +951,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         for (int i = 0; i < 4; ++i) glds16_asm_s(src, wo[i], dst + i * 1024);
     };
     auto stage_weights = [&](const char* wb, int kc, int tap, int buf) { stage_w(wb, cin, woff, kc, tap, buf); };
+    auto stage_weights_piece = [&](const char* wb, int kc, int tap, int buf, int i) {
+        const char* src = wb + ((int64_t)tap * a.CoutPad * cin + (int64_t)kc * kBK) * 2;
+        glds16_asm_s(src, woff[i], smem + buf * 16384 + (wv * 4) * 1024 + i * 1024);
+    };
     auto stage_halo = [&](const char* xb, int kc) {
         const char* src = xb + (int64_t)kc * (kBK * 2);
 #pragma unroll
@@ -1008,7 +1016,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         // Rolling fragment pipeline: 8 groups of 8 MFMAs (2 A fragments x 4 B fragments); A pairs are read two
         // groups ahead into a 3-slot ring, the second half's B fragments during group 1; `stage_next` issues the
         // next step's weight DMA after the first reads so its issue cost overlaps their LDS latency.
-        auto mma_step = [&](const char* wt, const char* be, const char* bo, auto&& stage_next) {
+        auto mma_step = [&](const char* wt, const char* be, const char* bo, auto&& stage_next, auto&& stage_piece) {
             f16x8 ar[RING][2], bq[2][4];
             auto read_a = [&](int g, f16x8 (&dst)[2]) {
                 const int ks = g >> 2, jp = g & 3;
@@ -1044,6 +1052,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                         acc[2 * jp + jj][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                             ar[g % RING][jj], bq[ks][n], acc[2 * jp + jj][n], 0, 0, 0);
                 if (!(NOPRIO)) __builtin_amdgcn_s_setprio(0);
+                if (DMA_SPREAD == 1 && g < 4) stage_piece(g);
+                if (DMA_SPREAD == 2 && (g & 1) == 0) stage_piece(g >> 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -1076,7 +1086,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 mma_step(smem + (kc & 1) * 16384, be, bo, [&] {
                     if (kc + 1 < nds) stage_w(dwb, dcin, woff_x, kc + 1, 0, (kc + 1) & 1);
                     else stage_w(cur.wb, cin, woff, 0, 0, (kc + 1) & 1);            // conv2's first step
-                });
+                }, [&](int) {});
                 __builtin_amdgcn_s_barrier();                 // every wave has consumed this chunk's fragments
                 asm volatile("" ::: "memory");
                 if (kc + 1 < nds) {
@@ -1138,17 +1148,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 asm volatile("" ::: "memory");
                 const char *be, *bo;
                 b_ptrs(tap, be, bo);
+                const bool more = k + 1 < nk;
+                const bool wrap = tap == 8;
+                const int tap1 = more ? (wrap ? 0 : tap + 1) : 0;
+                const int kc1 = more ? (wrap ? kc + 1 : kc) : 0;
+                const char* wsrc = more ? cur.wb : nwb;
                 mma_step(smem + ((kbase + k) & 1) * 16384, be, bo, [&] {
                     // the next K step's weights into the other buffer; on a tile's last step that is the
-                    // next tile's first step (persistent variant only)
-                    const bool more = k + 1 < nk;
-                    const bool wrap = tap == 8;
-                    const int tap1 = more ? (wrap ? 0 : tap + 1) : 0;
-                    const int kc1 = more ? (wrap ? kc + 1 : kc) : 0;
-                    const char* wsrc = more ? cur.wb : nwb;
+                    // next tile's first step (persistent variant only).
                     // nothing to stage on the very last step: no DMA is then in flight when the epilogue
                     // starts, so the workgroup can retire without waiting for its output stores
-                    if (more || has_next) stage_weights(wsrc, kc1, tap1, (kbase + k + 1) & 1);
+                    if (DMA_SPREAD == 0 && (more || has_next)) stage_weights(wsrc, kc1, tap1, (kbase + k + 1) & 1);
+                }, [&](int i) {
+                    if (more || has_next) stage_weights_piece(wsrc, kc1, tap1, (kbase + k + 1) & 1, i);
                 });
             }
             if ((next_chunk || has_next) && !(a.dbg & 32)) {     // dbg 32: timing experiment without the reload

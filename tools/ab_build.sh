@@ -15,5 +15,6 @@ $HIPCC $COMMON -ffp-contract=off -c $SRC/preprocess.hip -o $OUT/obj_$NAME/prepro
 $HIPCC $COMMON "$@" -x hip -c $SRC/engine.cpp -o $OUT/obj_$NAME/engine.o
 $HIPCC $COMMON -ffp-contract=off -c $SRC/beam_search.cpp -o $OUT/obj_$NAME/beam_search.o
 $HIPCC $COMMON -ffp-contract=off -c $SRC/ngram_lm.cpp -o $OUT/obj_$NAME/ngram_lm.o
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/$NAME.so $OUT/obj_$NAME/*.o -lpthread
+$HIPCC $COMMON -x hip -c $SRC/gather.cpp -o $OUT/obj_$NAME/gather.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/$NAME.so $OUT/obj_$NAME/*.o -lpthread -ldl
 echo $OUT/$NAME.so
