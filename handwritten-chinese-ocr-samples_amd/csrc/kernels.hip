@@ -14,7 +14,8 @@
 #endif
 #ifndef DMA_SPREAD
 #define DMA_SPREAD 0   // A/B build switch: 0 = a step's 4 weight-DMA pieces right after the first fragment reads; 1 = one piece
-                       // after each of MFMA groups 0..3; 2 = after groups 0, 2, 4, 6 (issue cost in the MFMAs' shadow)
+                       // after each of MFMA groups 0..3; 2 = after groups 0, 2, 4, 6 (issue cost in the MFMAs' shadow);
+                       // 3 = all four BEFORE the first fragment reads
 #endif
 #ifndef NOPRIO
 #define NOPRIO 0       // A/B build switch (tools/ab_build.sh): 1 drops the s_setprio around MFMA groups
@@ -1030,13 +1031,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                     dst[n] = *(const f16x8*)((((n & 1) ^ ks) ? bo : be) + n * (S * 128));
             };
             __builtin_amdgcn_sched_barrier(0);
+            if (DMA_SPREAD == 3) { stage_next(); __builtin_amdgcn_sched_barrier(0); }      // (A/B: DMA before the first reads)
             read_b(0, bq[0]);
             read_a(0, ar[0]);
             __builtin_amdgcn_sched_barrier(0);
             read_a(1, ar[1]);
             if (RING > 3) read_a(2, ar[2]);
             __builtin_amdgcn_sched_barrier(0);
-            stage_next();
+            if (DMA_SPREAD != 3) stage_next();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
@@ -1158,7 +1160,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                     // next tile's first step (persistent variant only).
                     // nothing to stage on the very last step: no DMA is then in flight when the epilogue
                     // starts, so the workgroup can retire without waiting for its output stores
-                    if (DMA_SPREAD == 0 && (more || has_next)) stage_weights(wsrc, kc1, tap1, (kbase + k + 1) & 1);
+                    if ((DMA_SPREAD == 0 || DMA_SPREAD == 3) && (more || has_next)) stage_weights(wsrc, kc1, tap1, (kbase + k + 1) & 1);
                 }, [&](int i) {
                     if (more || has_next) stage_weights_piece(wsrc, kc1, tap1, (kbase + k + 1) & 1, i);
                 });
