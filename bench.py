@@ -322,6 +322,15 @@ def main():
                                       source=meta_source("trained")),
                 "note": PARITY_NOTE["trained"]}
             del m3
+            tc = result["trained_checkpoint"]
+            # the figure that meets north_star's "decoded text exact" on the timed mode, stated in one place
+            result["text_exact_vs_reference"] = {
+                "mode": args.precision, "checkpoint": "trained-like (peaky logits)", "value": tc["value"], "unit": "lines/s",
+                "ms_per_step": tc["ms_per_step"],
+                "exact_lines": "%d/%d" % (tc["parity_vs_cpu"]["exact_lines"], tc["parity_vs_cpu"]["lines"]),
+                "random_head_checkpoint": "f16 %d/%d lines, f16x3 %s lines (near-tie-rich logits, see parity_note)" % (
+                    result.get("parity_vs_cpu", {}).get("exact_lines", -1), n_global,
+                    ("%d/%d" % (result["parity_vs_cpu_f16x3"]["exact_lines"], n_global)) if "parity_vs_cpu_f16x3" in result else "n/a")}
     if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 of the 1-GPU run only
         # the CPU restatement (bit-equal to the reference here) on B=4 lines of the same
         # workload, 1 warm-up + 3 timed passes, all host cores of the box
