@@ -1,3 +1,5 @@
+"""Diagnostic (lives under tests/ because it uses the oracle as the checker): f16x3 logits / text vs the oracle on a small
+unequal-width batch.  python tests/diag_f16x3_check.py"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,6 @@
-"""Stage-by-stage comparison of the engine against the oracle (run on the GPU box).
-    python tools/gpu_debug.py [W] [B]
+"""Diagnostic (lives under tests/ because it uses the oracle as the checker): stage-by-stage comparison of the engine
+against the oracle, run on the GPU box.
+    python tests/diag_stage_bisect.py [W] [B]
 """
 import os
 import sys

@@ -8,8 +8,7 @@ reduced-precision error), which the random head cannot offer. Output: synth_head
 committed next to synth_bn_calib.npz; the fixtures for it come from the REAL reference (make_golden_c2.py
 --checkpoint trained).
 
-    python tools/fit_trained_head.py --backend engine --train-lines 1536      (GPU box; features in f16x3 mode)
-    python tools/fit_trained_head.py --backend oracle --train-lines 24 --width 512 --classes 16   (CPU rehearsal)
+    python tools/fit_trained_head.py --train-lines 768 --classes 8      (GPU box; trunk features from the engine in f16x3 mode)
 """
 import argparse
 import json
@@ -60,16 +59,13 @@ class Features(object):
             if act.size != n * 2048 * imgs.shape[2]:
                 raise ValueError("batch of %d lines was split into internal passes: lower --batch" % n)
         else:
-            from oracle import hctr_ref
-            taps = {}
-            hctr_ref.forward(self.sd, synth.normalize_pad(imgs), taps)
-            act = taps["stage4"].numpy()
+            raise ValueError("only the engine backend exists (the oracle is test infrastructure)")
         return np.ascontiguousarray(act.transpose(0, 3, 1, 2).reshape(n, imgs.shape[2], 2048))
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--backend", default="engine", choices=["engine", "oracle"])
+    ap.add_argument("--backend", default="engine", choices=["engine"])
     ap.add_argument("--train-lines", type=int, default=1536)
     ap.add_argument("--eval-lines", type=int, default=64)
     ap.add_argument("--width", type=int, default=2000)
@@ -132,7 +128,7 @@ def main():
     Wev = w16.astype(np.float32)
     ok = edits = nchar = 0
     margins = []
-    from oracle import ctc_ref
+    import bench
     f16 = Features("engine", "f16") if args.backend == "engine" else None
     flips = lines_diff = runs = 0
     max_dlogit = 0.0
@@ -156,7 +152,7 @@ def main():
             text = decode(am[i])
             want = synth.font_truth_text(truth[s + i], W, chars)
             ok += text == want
-            edits += ctc_ref.edit_distance(text, want)
+            edits += bench.edit_distance(text, want)
             nchar += len(want)
             runs += len(text)
             if f16 is not None:
