@@ -151,6 +151,9 @@ SIGNATURES = [
     ("hctr_load_tensor", _I, [_VP, ctypes.c_char_p, _VP, c_i64p, _I, _I]),
     ("hctr_finalize_weights", _I, [_VP]),
     ("hctr_set_precision", _I, [_VP, _I]),
+    ("hctr_set_guard", _I, [_VP, ctypes.c_double, ctypes.c_double]),
+    ("hctr_last_guard", _I, [_VP, c_i64p, c_i64p, _VP, _VP, _VP, _I64]),
+    ("hctr_lines_per_pass", _I, [_VP, _I, _I, _I]),
     ("hctr_forward_logits", _I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I]),
     ("hctr_greedy", _I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _VP]),
     ("hctr_decode_greedy_logits", _I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP]),

@@ -278,17 +278,27 @@ class ctc_codec(object):
             depth = params.search_depth
             cdict = self.dict
 
+            last = {}                                    # the LM's answer of a call that asked for more slots
+
             def next_cb(user, n, ids, offs, kk, out_ids):
                 try:
-                    prefixes = ["".join(chars[ids[j]] for j in range(offs[i], offs[i + 1])) for i in range(n)]
-                    words = tfm.next_k_words(prefixes, k=depth, char_based=True)
+                    key = (n, tuple(ids[j] for j in range(offs[n])), tuple(offs[i] for i in range(n + 1)))
+                    if last.get("key") == key:
+                        words = last["words"]
+                    else:
+                        prefixes = ["".join(chars[ids[j]] for j in range(offs[i], offs[i + 1])) for i in range(n)]
+                        words = [list(w) for w in tfm.next_k_words(prefixes, k=depth, char_based=True)]
                     # the reference chains whatever the LM returns (utils/ctc_codec.py:225-226): a shorter list is
-                    # padded with the <unknown> id, which the search skips like the reference does (:238-239)
+                    # padded with the <unknown> id, which the search skips like the reference does (:238-239); a
+                    # longer one makes the search call again with as many slots as the longest list needs
+                    need = max([len(w) for w in words] + [0])
+                    if need > kk:
+                        last["key"], last["words"] = key, words
+                        return need
+                    last.clear()
                     unk = len(chars) - 1
                     for i in range(n):
-                        wl = list(words[i])
-                        if len(wl) > kk:
-                            raise ValueError("next_k_words returned %d words for k=%d" % (len(wl), kk))
+                        wl = words[i]
                         for j in range(kk):
                             out_ids[i * kk + j] = cdict[wl[j]] if j < len(wl) else unk
                     return 0

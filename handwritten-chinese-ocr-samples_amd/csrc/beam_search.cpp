@@ -198,6 +198,7 @@ struct Scratch {                 // per line, reused across steps
     std::vector<int> stamp;
     int epoch = 0;
     std::vector<int32_t> ids, offs, ling;
+    int ling_stride = 0;         // slots per beam in ling (search_depth, or more when the LM returned longer lists)
     std::vector<double> scores, tot;
     std::vector<int> order;
 };
@@ -215,9 +216,19 @@ int beam_step(const hctr_beam_params& P, const LineInput& in, int t, Trie& trie,
             trie.append_labels(h.node, S.ids);
             S.offs.push_back((int32_t)S.ids.size());
         }
-        S.ling.assign((size_t)beams.size() * P.search_depth, 0);
-        const int rc = P.next_cb(P.user, (int)beams.size(), S.ids.data(), S.offs.data(), P.search_depth, S.ling.data());
-        if (rc != 0) return rc;
+        // the reference chains WHATEVER list the LM returns (:225-226): the callback fills up to `slots` labels per
+        // beam (short lists padded with the <unknown> id, which is skipped below) and returns 0, or - when some list is
+        // longer - the number of slots it needs, and is then called again with that many
+        int slots = std::max(P.search_depth, S.ling_stride);
+        for (int attempt = 0;; ++attempt) {
+            S.ling.assign((size_t)beams.size() * slots, 0);
+            const int rc = P.next_cb(P.user, (int)beams.size(), S.ids.data(), S.offs.data(), slots, S.ling.data());
+            if (rc == 0) break;
+            if (rc < 0) return rc;
+            if (rc <= slots || attempt >= 2) return HCTR_ERR_ARG;       // (a callback that keeps asking is broken)
+            slots = rc;
+        }
+        S.ling_stride = slots;
     }
     // Step 2: extend (:229-265). gen keeps first-touch order (Python dict insertion order).
     std::vector<Hyp>& gen = S.gen;
@@ -238,7 +249,7 @@ int beam_step(const hctr_beam_params& P, const LineInput& in, int t, Trie& trie,
         const Hyp h = beams[bi];
         const double hprob = h.prob();
         const int tail = trie.nodes[h.node].label;               // -1 for the empty prefix
-        const int nl = (P.next_cb && h.node != 0) ? P.search_depth : 0;
+        const int nl = (P.next_cb && h.node != 0) ? S.ling_stride : 0;
         for (int ci = 0; ci < ncand + nl; ++ci) {
             int idx;
             double p;
@@ -246,7 +257,7 @@ int beam_step(const hctr_beam_params& P, const LineInput& in, int t, Trie& trie,
                 idx = cands[ci];
                 p = (double)plog[ci];
             } else {
-                idx = S.ling[bi * P.search_depth + (ci - ncand)];
+                idx = S.ling[bi * (size_t)S.ling_stride + (ci - ncand)];
                 if (idx < 0 || idx >= in.C) return HCTR_ERR_ARG;
                 if (idx >= unk) continue;
                 p = (double)in.full_logp[((size_t)t * in.B + in.b) * in.C + idx];

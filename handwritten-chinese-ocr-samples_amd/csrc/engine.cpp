@@ -81,11 +81,29 @@ struct Workspace {
     double* esum = nullptr;         // [P][B*W]
     int32_t* overflow = nullptr;    // [1]
     int32_t* tile_ctrs = nullptr;   // [64 launches][8 XCDs] tile queues of the persistent conv variant (HCTR_PERSIST=2)
+    // guarded precision (WS_GUARD): runner-up / |logit| partials of the fused head, per-column and per-line figures
+    float* amax_val2 = nullptr;     // [P][B*W]
+    float* amax_abs = nullptr;      // [P][B*W]
+    float* col_margin = nullptr;    // [B*W] top-1 minus top-2 logit
+    float* col_abs = nullptr;       // [B*W] max |logit|
+    float* line_guard = nullptr;    // [B][2] = {min margin, max |logit|} per line
     int features = 0;               // WS_* sets carved into this layout
+    bool split = false;             // layout of the f16x3 planes (3x the activation channels)
 };
 
 // optional parts of a workspace layout (carved behind the core buffers, so adding one moves nothing)
-enum WsFeature { WS_S0 = 1, WS_LOGITS = 2, WS_BEAM = 4 };
+enum WsFeature { WS_S0 = 1, WS_LOGITS = 2, WS_BEAM = 4, WS_GUARD = 8 };
+
+// one resident set of device weights in kernel layouts; set 0 = f16, set 1 = f16x3 ([w_hi | w_hi | w_lo] rows)
+struct WeightSet {
+    float* stem_w = nullptr;
+    float* stem_b = nullptr;
+    ConvW conv0_2;
+    std::vector<BlockW> blocks[4];
+    ConvW stage_conv[4];
+    ConvW head;
+    bool built = false;
+};
 
 struct ProfEntry {
     std::string name;
@@ -102,13 +120,9 @@ struct hctr_ctx {
     std::string err;
     std::map<std::string, HostTensor> host;
     bool finalized = false;
-    // device weights
-    float* stem_w = nullptr;
-    float* stem_b = nullptr;
-    ConvW conv0_2;
-    std::vector<BlockW> blocks[4];
-    ConvW stage_conv[4];
-    ConvW head;
+    // device weights: the sets the precision mode chosen before hctr_finalize_weights needs (mode 2 keeps both)
+    WeightSet wset[2];
+    const WeightSet& wts() const { return wset[split ? 1 : 0]; }
     std::vector<void*> wallocs;
     // ONE device arena holds the workspace of whatever (lines, width) shape is active: a new shape re-carves the
     // pointers and re-zeroes the stored conv borders (a small kernel), it does not allocate - ragged workloads present a
@@ -124,7 +138,20 @@ struct hctr_ctx {
     // f16x3 precision mode: every activation and weight is carried as hi + lo fp16 pairs; a conv sees
     // tripled input channels [x_hi | x_lo | x_hi] against weight rows [w_hi | w_hi | w_lo], so the MFMA
     // main loops are unchanged and the products w_hi*x_hi + w_hi*x_lo + w_lo*x_hi are summed in fp32.
+    // `split` is the arithmetic of the pass being run; `mode` is what the caller asked for: 0 = f16, 1 = f16x3,
+    // 2 = guarded ("auto"): every line runs in f16, the fused head also yields each column's top-1/top-2 logit margin,
+    // and the lines with a column whose margin is within twice the f16 logit tolerance (guard_rel * max|logit of the
+    // line| + guard_abs - the tolerance the parity suite asserts) are run again in f16x3 at the same padded width.
+    int mode = 0;
     bool split = false;
+    double guard_rel = 0.01, guard_abs = 0.05;
+    // guard figures of the last call in mode 2 (per line of that call's batch)
+    std::vector<float> g_margin, g_scale;
+    std::vector<uint8_t> g_flag;
+    int64_t g_flagged_total = 0, g_lines_total = 0;      // running totals over the context's lifetime
+    std::vector<std::vector<int32_t>> h_widths;          // gathered widths of this call's passes (source of async copies:
+                                                         // kept until the next call; every call drains the stream first)
+    std::vector<int32_t> h_labels, h_lengths;            // labels of a re-run pass before they are scattered
     int chm() const { return split ? 3 : 1; }      // channel multiplier of activation buffers
     bool fuse_se = true;
     std::string stamp_layer;         // hctr_debug_stamps: layer whose workgroups are time-stamped (diagnostic)
@@ -318,7 +345,7 @@ int build_se(hctr_ctx* c, const std::string& key, int ch, SeW* out) {
     return HCTR_OK;
 }
 
-int build_stem(hctr_ctx* c) {
+int build_stem(hctr_ctx* c, WeightSet& ws) {
     const HostTensor *w, *b, *g, *beta, *mean, *var;
     TRY(need(c, "cnn.conv0_1.weight", {64, 1, 3, 3}, &w));
     TRY(need(c, "cnn.conv0_1.bias", {64}, &b));
@@ -332,17 +359,17 @@ int build_stem(hctr_ctx* c) {
         for (int t = 0; t < 9; ++t) hw[co * 9 + t] = (float)((double)w->data[co * 9 + t] * sc);
         hb[co] = (float)(((double)b->data[co] - (double)mean->data[co]) * sc + (double)beta->data[co]);
     }
-    TRY(dev_alloc(c, c->wallocs, &c->stem_w, hw.size(), false));
-    TRY(dev_alloc(c, c->wallocs, &c->stem_b, hb.size(), false));
-    HIP_TRY(c, hipMemcpyAsync(c->stem_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->stem_b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice, c->stream));
+    TRY(dev_alloc(c, c->wallocs, &ws.stem_w, hw.size(), false));
+    TRY(dev_alloc(c, c->wallocs, &ws.stem_b, hb.size(), false));
+    HIP_TRY(c, hipMemcpyAsync(ws.stem_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(ws.stem_b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return HCTR_OK;
 }
 
 // self.linear (models/handwritten_ctr_model.py:169,175). The reference's feature index is
 // d = c*4 + h (flatten(1,2) of [B,C,H,W], :173); the engine's head input is [pixel][h*512 + c].
-int build_head(hctr_ctx* c) {
+int build_head(hctr_ctx* c, WeightSet& ws) {
     const HostTensor *w, *b;
     const int C = c->num_classes;
     TRY(need(c, "linear.weight", {C, kFeat}, &w));
@@ -372,11 +399,11 @@ int build_head(hctr_ctx* c) {
                 }
         }
     for (int n = 0; n < C; ++n) hb[n] = b->data[n];
-    c->head.cin = kf; c->head.cout = C; c->head.coutPad = cpad; c->head.taps = 1;
-    TRY(dev_alloc(c, c->wallocs, &c->head.w, hw.size(), false));
-    TRY(dev_alloc(c, c->wallocs, &c->head.bias, hb.size(), false));
-    HIP_TRY(c, hipMemcpyAsync(c->head.w, hw.data(), hw.size() * sizeof(half_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->head.bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice, c->stream));
+    ws.head.cin = kf; ws.head.cout = C; ws.head.coutPad = cpad; ws.head.taps = 1;
+    TRY(dev_alloc(c, c->wallocs, &ws.head.w, hw.size(), false));
+    TRY(dev_alloc(c, c->wallocs, &ws.head.bias, hb.size(), false));
+    HIP_TRY(c, hipMemcpyAsync(ws.head.w, hw.data(), hw.size() * sizeof(half_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(ws.head.bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return HCTR_OK;
 }
@@ -386,13 +413,23 @@ int build_head(hctr_ctx* c) {
 // ---------------------------------------------------------------------------------------------
 inline int64_t act_elems(int B, int H, int Wa, int C) { return (int64_t)B * (H + 2) * Wa * C; }
 
+// class parts per row written by the fused head epilogues: n-tiles x wave columns. The 256x256 head tile gives
+// cpad/128 parts, the 128x128 tile (HCTR_BIG_TILES=0, or cpad not a multiple of 256) cpad/64: buffers are sized for
+// the larger figure, launches use head_parts(c).
+inline int head_parts_max(const hctr_ctx* c) { return c->cpad / 64; }
+inline int head_parts(const hctr_ctx* c) {
+    const int hbm = (c->big_tiles && c->cpad % 256 == 0) ? 256 : 128;
+    return (c->cpad / hbm) * kLinearWN;
+}
+
 int ensure_workspace(hctr_ctx* c, int B, int W, int features = 0) {
     c->ws_sticky |= features;
-    if (c->ws.B == B && c->ws.W == W && (c->ws.features & c->ws_sticky) == c->ws_sticky) return HCTR_OK;
-    const bool same_shape = c->ws.B == B && c->ws.W == W;
-    const int feat = c->ws_sticky;
+    const bool same_shape = c->ws.B == B && c->ws.W == W && c->ws.split == c->split;
+    int feat = c->ws_sticky;
+    if (c->fuse_stem && !c->split) feat &= ~WS_S0;        // (mode 2 alternates layouts: conv0_1's buffer only where it is used)
+    if (same_shape && (c->ws.features & feat) == feat) return HCTR_OK;
     Workspace ws;
-    ws.B = B; ws.W = W; ws.features = feat;
+    ws.B = B; ws.W = W; ws.features = feat; ws.split = c->split;
     const int tilesW = (W + kTileW - 1) / kTileW;        // 16-column tiles (upper bound on tiles per row)
     const int Wa = (W + 31) / 32 * 32 + 2;               // room for the widest (32-column) tile + border
     ws.Wa = Wa;
@@ -424,8 +461,9 @@ int ensure_workspace(hctr_ctx* c, int B, int W, int features = 0) {
     A(&ws.se_mean, (size_t)B * 512);
     A(&ws.se_counter, (size_t)B);
     A(&ws.colidx, cols);
-    A(&ws.amax_val, cols * (c->cpad / 64));
-    A(&ws.amax_idx, cols * (c->cpad / 64));
+    const size_t P = (size_t)head_parts_max(c);           // class parts per row of the fused head epilogues
+    A(&ws.amax_val, cols * P);
+    A(&ws.amax_idx, cols * P);
     A(&ws.labels, cols);
     A(&ws.lengths, (size_t)B);
     A(&ws.tile_ctrs, (size_t)64 * 8);
@@ -433,8 +471,14 @@ int ensure_workspace(hctr_ctx* c, int B, int W, int features = 0) {
     if (feat & WS_S0) A(&ws.s0, (size_t)act_elems(B, 128, Wa, 64 * m));
     // [B*W][cpad] fp32 logits (3.8 GB at config 2): hctr_forward_logits and the HCTR_FUSE_* = 0 A/B paths only
     if (feat & WS_LOGITS) A(&ws.logits, cols * c->cpad);
+    if (feat & WS_GUARD) {                               // guarded precision: runner-up / |logit| partials and figures
+        A(&ws.amax_val2, cols * P);
+        A(&ws.amax_abs, cols * P);
+        A(&ws.col_margin, cols);
+        A(&ws.col_abs, cols);
+        A(&ws.line_guard, (size_t)2 * B);
+    }
     if (feat & WS_BEAM) {                                // scratch of the fused beam front end (kernels.h ConvArgs)
-        const size_t P = (size_t)c->cpad / 128;
         A(&ws.psum, P * cols);
         A(&ws.blank_logit, cols);
         A(&ws.row_thr, 2 * cols);
@@ -513,6 +557,7 @@ struct Prof {
 // whose entries of the same name hctr_last_profile adds up)
 inline void prof_reset(hctr_ctx* c) {
     if (c->profiling) { c->prof.clear(); c->ev_used = 0; }
+    c->h_widths.clear();                              // (the previous call drained the stream before it returned)
 }
 
 struct ActDesc {            // a padded NHWC activation
@@ -584,7 +629,7 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
         if (tile != TILE_64x256 || cw.taps != 9 || cw.cin != 64 || cw.coutPad != 64 || c->split)
             return fail(c, HCTR_ERR_STATE, "conv %s: stem fusion not applicable", name);
         a.img = ws.img; a.img_f32 = stem_img_f32; a.img_widths = stem_widths ? ws.widths : nullptr;
-        a.stem_w = c->stem_w; a.stem_b = c->stem_b;
+        a.stem_w = c->wts().stem_w; a.stem_b = c->wts().stem_b;
         HIP_TRY(c, launch_stem_conv0_2(a, c->stream));
     } else {
         HIP_TRY(c, launch_conv(a, tile, cw.taps, false, c->stream));
@@ -654,11 +699,12 @@ enum HeadMode { HEAD_LOGITS = 0, HEAD_ARGMAX = 1, HEAD_BEAM = 2 };
 
 // optional workspace parts a forward in this head mode uses. Callers pass them to ensure_workspace BEFORE the input
 // is staged: carving a part may move the arena, which would lose an image already copied into it.
-int ws_need(const hctr_ctx* c, HeadMode mode) {
+int ws_need(const hctr_ctx* c, HeadMode mode, bool guarded = false) {
     int need = 0;
     if (mode == HEAD_LOGITS) need |= WS_LOGITS;
     if (mode == HEAD_BEAM) need |= WS_BEAM;
     if (!(c->fuse_stem && !c->split)) need |= WS_S0;
+    if (guarded) need |= WS_GUARD;
     return need;
 }
 
@@ -666,8 +712,8 @@ int ws_need(const hctr_ctx* c, HeadMode mode) {
 void head_args(hctr_ctx* c, ConvArgs* out, ConvTile* tile) {
     const Workspace& ws = c->ws;
     ConvArgs a{};
-    a.x = ws.headin; a.w = c->head.w; a.bias = c->head.bias; a.y = ws.logits;
-    a.Cin = c->head.cin; a.Cout = c->num_classes; a.CoutPad = c->cpad;
+    a.x = ws.headin; a.w = c->wts().head.w; a.bias = c->wts().head.bias; a.y = ws.logits;
+    a.Cin = c->wts().head.cin; a.Cout = c->num_classes; a.CoutPad = c->cpad;
     a.M = (int64_t)ws.B * ws.W; a.ldo = c->cpad;
     *tile = (c->big_tiles && c->cpad % 256 == 0) ? TILE_256x256 : TILE_128x128;
     const int hbm = *tile == TILE_256x256 ? 256 : 128;
@@ -675,10 +721,14 @@ void head_args(hctr_ctx* c, ConvArgs* out, ConvTile* tile) {
     *out = a;
 }
 
-int run_forward(hctr_ctx* c, int img_f32, bool have_widths, HeadMode mode = HEAD_LOGITS) {
-    if ((c->ws.features & ws_need(c, mode)) != ws_need(c, mode))
+// guarded: also leave each line's {smallest top-1/top-2 logit margin, largest |logit|} in ws.line_guard (mode 2's
+// f16 passes; the figures come from the head epilogue's partials, or from the stored logits in HEAD_LOGITS mode)
+int run_forward(hctr_ctx* c, int img_f32, bool have_widths, HeadMode mode = HEAD_LOGITS, bool guarded = false) {
+    if ((c->ws.features & ws_need(c, mode, guarded)) != ws_need(c, mode, guarded) || c->ws.split != c->split)
         return fail(c, HCTR_ERR_STATE, "workspace lacks a part this forward needs (ensure_workspace before staging)");
     Workspace& ws = c->ws;
+    const WeightSet& wt = c->wts();
+    if (!wt.built) return fail(c, HCTR_ERR_STATE, "the weight set of this precision mode is not resident");
     Prof pf(c);
     if (c->persist_dynamic) {
         HIP_TRY(c, hipMemsetAsync(ws.tile_ctrs, 0, 64 * 8 * 4, c->stream));
@@ -686,22 +736,22 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths, HeadMode mode = HEAD
     }
     if (c->fuse_stem && !c->split) {
         // conv0_1's output (16 kB per pixel column) never reaches HBM: it is computed into conv0_2's LDS halo
-        TRY(run_conv(c, pf, "stem+conv0_2+pool", c->conv0_2, ActDesc{nullptr, 128, 64}, ws.x[1], 64, true, true, nullptr,
+        TRY(run_conv(c, pf, "stem+conv0_2+pool", wt.conv0_2, ActDesc{nullptr, 128, 64}, ws.x[1], 64, true, true, nullptr,
                      false, nullptr, nullptr, nullptr, nullptr, img_f32 ? 1 : 0, have_widths));
     } else {
         pf.begin("stem.conv0_1");
-        HIP_TRY(c, launch_stem(ws.img, img_f32, have_widths ? ws.widths : nullptr, c->stem_w, c->stem_b, ws.s0, ws.B,
+        HIP_TRY(c, launch_stem(ws.img, img_f32, have_widths ? ws.widths : nullptr, wt.stem_w, wt.stem_b, ws.s0, ws.B,
                                ws.W, ws.Wa, c->split, c->stream));
         pf.end();
-        TRY(run_conv(c, pf, "conv0_2+pool", c->conv0_2, ActDesc{ws.s0, 128, 64}, ws.x[1], 64, true, true, nullptr, false));
+        TRY(run_conv(c, pf, "conv0_2+pool", wt.conv0_2, ActDesc{ws.s0, 128, 64}, ws.x[1], 64, true, true, nullptr, false));
     }
     int cin = 64;
     for (int s = 1; s <= 4; ++s) {
         const int H = kStageH[s], planes = kStagePlanes[s - 1];
         ActDesc cur{ws.x[s], H, cin};
         int ci = -1;                              // index of the buffer holding `cur`; -1 = stage input
-        for (size_t i = 0; i < c->blocks[s - 1].size(); ++i) {
-            const BlockW& bw = c->blocks[s - 1][i];
+        for (size_t i = 0; i < wt.blocks[s - 1].size(); ++i) {
+            const BlockW& bw = wt.blocks[s - 1][i];
             char nm[48];
             snprintf(nm, sizeof(nm), "block%d.%zu", s, i);
             // three rotating buffers: t and o go to the two that do not hold the block input; the
@@ -715,32 +765,48 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths, HeadMode mode = HEAD
         char nm[32];
         snprintf(nm, sizeof(nm), "conv%d+pool", s);
         if (s < 4)
-            TRY(run_conv(c, pf, nm, c->stage_conv[s - 1], cur, ws.x[s + 1], H / 2, true, true, nullptr, false));
+            TRY(run_conv(c, pf, nm, wt.stage_conv[s - 1], cur, ws.x[s + 1], H / 2, true, true, nullptr, false));
         else
-            TRY(run_conv(c, pf, nm, c->stage_conv[s - 1], cur, ws.headin, H / 2, true, true, nullptr, true));
+            TRY(run_conv(c, pf, nm, wt.stage_conv[s - 1], cur, ws.headin, H / 2, true, true, nullptr, true));
         cin = planes;
     }
     // head GEMM
     ConvArgs a;
     ConvTile htile;
     head_args(c, &a, &htile);
+    auto line_guard = [&]() -> int {
+        pf.begin("line_guard");
+        HIP_TRY(c, launch_line_guard(ws.col_margin, ws.col_abs, ws.B, ws.W, ws.line_guard, c->stream));
+        pf.end();
+        return HCTR_OK;
+    };
     if (mode == HEAD_ARGMAX || mode == HEAD_BEAM) {
         a.y = nullptr;
         a.amax_val = ws.amax_val;
         a.amax_idx = ws.amax_idx;
+        if (guarded) { a.amax_val2 = ws.amax_val2; a.amax_abs = ws.amax_abs; }
         if (mode == HEAD_BEAM) { a.psum = ws.psum; a.blank_logit = ws.blank_logit; }
         pf.begin(mode == HEAD_BEAM ? "head.linear+partials" : "head.linear+argmax");
         HIP_TRY(c, launch_conv(a, htile, 1, true, c->stream));
         pf.end();
-        if (mode == HEAD_BEAM) return HCTR_OK;
+        if (mode == HEAD_BEAM && !guarded) return HCTR_OK;
         pf.begin("argmax_partials");
-        HIP_TRY(c, launch_argmax_partials(ws.amax_val, ws.amax_idx, a.ntiles * kLinearWN, a.M, ws.colidx, c->stream));
+        HIP_TRY(c, launch_argmax_partials(ws.amax_val, ws.amax_idx, a.ntiles * kLinearWN, a.M,
+                                          mode == HEAD_BEAM ? nullptr : ws.colidx, c->stream, a.amax_val2, a.amax_abs,
+                                          guarded ? ws.col_margin : nullptr, guarded ? ws.col_abs : nullptr));
         pf.end();
+        if (guarded) TRY(line_guard());
         return HCTR_OK;
     }
     pf.begin("head.linear");
     HIP_TRY(c, launch_conv(a, htile, 1, true, c->stream));
     pf.end();
+    if (guarded) {
+        pf.begin("row_guard");
+        HIP_TRY(c, launch_row_guard(ws.logits, c->cpad, a.M, c->num_classes, ws.col_margin, ws.col_abs, c->stream));
+        pf.end();
+        TRY(line_guard());
+    }
     return HCTR_OK;
 }
 
@@ -772,21 +838,31 @@ int beam_finish(hctr_ctx* c, int k, bool want_candidates, double thresh, int32_t
     return HCTR_OK;
 }
 
-int stage_input(hctr_ctx* c, const void* img, int img_dtype, int img_on_device, const int32_t* widths, int b0,
-                int nb, int Bfull, int W) {
+// Copy the lines `lines[0..nb)` of the caller's batch (and their widths) into the workspace. Runs of consecutive
+// lines become one copy each, so an ordinary pass (a contiguous range) is a single copy.
+int stage_input(hctr_ctx* c, const void* img, int img_dtype, int img_on_device, const int32_t* widths,
+                const int* lines, int nb, int W) {
     Workspace& ws = c->ws;
     const size_t esz = img_dtype == HCTR_F32 ? 4 : 1;
     const size_t per = (size_t)kImgH * W * esz;
-    const char* src = (const char*)img + (size_t)b0 * per;
-    HIP_TRY(c, hipMemcpyAsync(ws.img, src, per * nb, img_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                              c->stream));
-    if (widths) {
-        for (int i = 0; i < nb; ++i)
-            if (widths[b0 + i] < 1 || widths[b0 + i] > W)
-                return fail(c, HCTR_ERR_ARG, "widths[%d]=%d outside [1,%d]", b0 + i, widths[b0 + i], W);
-        HIP_TRY(c, hipMemcpyAsync(ws.widths, widths + b0, (size_t)nb * 4, hipMemcpyHostToDevice, c->stream));
+    const hipMemcpyKind kind = img_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    for (int i = 0; i < nb;) {
+        int j = i + 1;
+        while (j < nb && lines[j] == lines[j - 1] + 1) ++j;
+        HIP_TRY(c, hipMemcpyAsync((char*)ws.img + (size_t)i * per, (const char*)img + (size_t)lines[i] * per,
+                                  per * (size_t)(j - i), kind, c->stream));
+        i = j;
     }
-    (void)Bfull;
+    if (widths) {
+        c->h_widths.emplace_back((size_t)nb);
+        std::vector<int32_t>& hw = c->h_widths.back();
+        for (int i = 0; i < nb; ++i) {
+            const int32_t w = widths[lines[i]];
+            if (w < 1 || w > W) return fail(c, HCTR_ERR_ARG, "widths[%d]=%d outside [1,%d]", lines[i], w, W);
+            hw[(size_t)i] = w;
+        }
+        HIP_TRY(c, hipMemcpyAsync(ws.widths, hw.data(), (size_t)nb * 4, hipMemcpyHostToDevice, c->stream));
+    }
     return HCTR_OK;
 }
 
@@ -801,13 +877,46 @@ int check_forward_args(hctr_ctx* c, const void* img, int img_dtype, int B, int W
 
 // lines per internal pass: at most max_cols pixel columns, balanced so every pass of a batch has the
 // same shape (one cached workspace per (B, W) instead of a second one for a short tail)
-int sub_batch(hctr_ctx* c, int B, int W) {
-    int64_t nb = (c->max_cols / c->chm()) / W;
+int sub_batch(hctr_ctx* c, int B, int W, bool split) {
+    int64_t nb = (c->max_cols / (split ? 3 : 1)) / W;
     if (nb < 1) nb = 1;
     if (nb >= B) return B;
     const int64_t passes = (B + nb - 1) / nb;
     return (int)((B + passes - 1) / passes);
 }
+
+// mode 2: which lines of the finished f16 sweep must run again in f16x3. gbuf = [B][2] {min margin, max |logit|}.
+// A line is certain when EVERY column's top-1/top-2 margin exceeds twice the f16 logit tolerance
+// tol = guard_rel * (max |logit| of the line) + guard_abs: a flip needs err(top1) + err(other) > margin, and each
+// error is bounded by tol (the bound tests/test_gpu_parity.py asserts for the f16 mode). NaN / inf figures flag.
+std::vector<int> guard_decide(hctr_ctx* c, const std::vector<float>& gbuf, int B) {
+    c->g_margin.resize((size_t)B); c->g_scale.resize((size_t)B); c->g_flag.assign((size_t)B, 0);
+    std::vector<int> flagged;
+    for (int b = 0; b < B; ++b) {
+        const float mg = gbuf[2 * (size_t)b], sc = gbuf[2 * (size_t)b + 1];
+        c->g_margin[(size_t)b] = mg;
+        c->g_scale[(size_t)b] = sc;
+        const double thr = 2.0 * (c->guard_rel * (double)sc + c->guard_abs);
+        if (!((double)mg > thr)) {
+            c->g_flag[(size_t)b] = 1;
+            flagged.push_back(b);
+        }
+    }
+    c->g_lines_total += B;
+    c->g_flagged_total += (int64_t)flagged.size();
+    return flagged;
+}
+
+void guard_clear(hctr_ctx* c) {
+    c->g_margin.clear(); c->g_scale.clear(); c->g_flag.clear();
+}
+
+// the arithmetic of a call's passes returns to the mode's own on every exit path
+struct SplitScope {
+    hctr_ctx* c;
+    explicit SplitScope(hctr_ctx* ctx) : c(ctx) { c->split = c->mode == 1; }
+    ~SplitScope() { c->split = c->mode == 1; }
+};
 
 }  // namespace
 
@@ -821,7 +930,7 @@ extern "C" {
 #endif
 // ends in the hash of the sources this binary was built from (_lib.py source_hash: stale-binary detection)
 const char* hctr_version(void) {
-    return "hctr-hip 0.2 (gfx950, f16 storage / f16 MFMA / f32 accumulate; optional f16x3 split precision) "
+    return "hctr-hip 0.3 (gfx950, f16 storage / f16 MFMA / f32 accumulate; f16x3 split precision; guarded mode) "
            "hctr-src=" HCTR_SRC_HASH;
 }
 
@@ -849,7 +958,11 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
         }
         if (const char* bt = getenv("HCTR_BIG_TILES")) c->big_tiles = atoi(bt) != 0;
         if (const char* hm = getenv("HCTR_HALO")) c->halo_mode = atoi(hm);
-        if (const char* pr = getenv("HCTR_PRECISION")) c->split = std::string(pr) == "f16x3";
+        if (const char* pr = getenv("HCTR_PRECISION")) {
+            const std::string m(pr);
+            c->mode = m == "f16x3" ? 1 : (m == "auto" ? 2 : 0);
+            c->split = c->mode == 1;
+        }
         if (const char* fs = getenv("HCTR_FUSE_SE")) c->fuse_se = atoi(fs) != 0;
         if (const char* fa = getenv("HCTR_FUSE_ARGMAX")) c->fuse_argmax = atoi(fa) != 0;
         if (const char* fd = getenv("HCTR_FUSE_DS")) c->fuse_ds = atoi(fd) != 0;
@@ -910,28 +1023,40 @@ int hctr_finalize_weights(hctr_ctx* c) {
         if (!c) return HCTR_ERR_ARG;
         if (c->finalized) return fail(c, HCTR_ERR_STATE, "weights already finalized");
         HIP_TRY(c, hipSetDevice(c->device));
-        TRY(build_stem(c));
-        TRY(build_conv(c, "cnn.conv0_2", "cnn.bn0_2", 64, 64, 3, true, 64, &c->conv0_2));
-        int inpl = 64;
-        for (int s = 0; s < 4; ++s) {
-            const int planes = kStagePlanes[s];
-            c->blocks[s].resize(kStageBlocks[s]);
-            for (int i = 0; i < kStageBlocks[s]; ++i) {
-                BlockW& bw = c->blocks[s][i];
-                const std::string p = "cnn.block" + std::to_string(s + 1) + "." + std::to_string(i);
-                if (i == 0 && inpl != planes) {
-                    bw.has_ds = true;
-                    TRY(build_conv(c, p + ".downsample.0", p + ".downsample.1", inpl, planes, 1, false, 128, &bw.ds));
+        // the f16 set for modes 0 and 2, the f16x3 set for modes 1 and 2 (build_* read c->split for the row layout)
+        auto build_set = [&](bool split) -> int {
+            c->split = split;
+            WeightSet& ws = c->wset[split ? 1 : 0];
+            TRY(build_stem(c, ws));
+            TRY(build_conv(c, "cnn.conv0_2", "cnn.bn0_2", 64, 64, 3, true, 64, &ws.conv0_2));
+            int inpl = 64;
+            for (int s = 0; s < 4; ++s) {
+                const int planes = kStagePlanes[s];
+                ws.blocks[s].assign(kStageBlocks[s], BlockW());
+                for (int i = 0; i < kStageBlocks[s]; ++i) {
+                    BlockW& bw = ws.blocks[s][i];
+                    const std::string p = "cnn.block" + std::to_string(s + 1) + "." + std::to_string(i);
+                    if (i == 0 && inpl != planes) {
+                        bw.has_ds = true;
+                        TRY(build_conv(c, p + ".downsample.0", p + ".downsample.1", inpl, planes, 1, false, 128, &bw.ds));
+                    }
+                    TRY(build_conv(c, p + ".conv1", p + ".bn1", inpl, planes, 3, true, 128, &bw.conv1));
+                    TRY(build_conv(c, p + ".conv2", p + ".bn2", planes, planes, 3, true, 128, &bw.conv2));
+                    TRY(build_se(c, p + ".se", planes, &bw.se));
+                    inpl = planes;
                 }
-                TRY(build_conv(c, p + ".conv1", p + ".bn1", inpl, planes, 3, true, 128, &bw.conv1));
-                TRY(build_conv(c, p + ".conv2", p + ".bn2", planes, planes, 3, true, 128, &bw.conv2));
-                TRY(build_se(c, p + ".se", planes, &bw.se));
-                inpl = planes;
+                const std::string k = "cnn.conv" + std::to_string(s + 1);
+                TRY(build_conv(c, k, "cnn.bn" + std::to_string(s + 1), planes, planes, 3, true, 128, &ws.stage_conv[s]));
             }
-            const std::string k = "cnn.conv" + std::to_string(s + 1);
-            TRY(build_conv(c, k, "cnn.bn" + std::to_string(s + 1), planes, planes, 3, true, 128, &c->stage_conv[s]));
-        }
-        TRY(build_head(c));
+            TRY(build_head(c, ws));
+            ws.built = true;
+            return HCTR_OK;
+        };
+        int rc = HCTR_OK;
+        if (c->mode != 1) rc = build_set(false);
+        if (rc == HCTR_OK && c->mode != 0) rc = build_set(true);
+        c->split = c->mode == 1;
+        TRY(rc);
         // strict load: no unexpected float keys (load_state_dict(strict=True), test.py:153)
         for (auto& kv : c->host)
             if (!kv.second.used)
@@ -945,10 +1070,54 @@ int hctr_finalize_weights(hctr_ctx* c) {
 int hctr_set_precision(hctr_ctx* c, int mode) {
     return guard(c, [&]() -> int {
         if (!c) return HCTR_ERR_ARG;
-        if (mode != 0 && mode != 1) return fail(c, HCTR_ERR_ARG, "precision mode must be 0 (f16) or 1 (f16x3)");
-        if (c->finalized) return fail(c, HCTR_ERR_STATE, "precision must be chosen before hctr_finalize_weights");
+        if (mode < 0 || mode > 2) return fail(c, HCTR_ERR_ARG, "precision mode must be 0 (f16), 1 (f16x3) or 2 (guarded: f16, "
+                                                                 "uncertain lines again in f16x3)");
+        if (c->finalized) {
+            // after the weights are resident the mode may still move between the modes whose weight set(s) exist
+            // (a context finalized in mode 2 holds both sets and serves all three)
+            const bool need0 = mode != 1, need1 = mode != 0;
+            if ((need0 && !c->wset[0].built) || (need1 && !c->wset[1].built))
+                return fail(c, HCTR_ERR_STATE, "precision mode %d needs a weight set this context did not build: choose it "
+                                               "(or mode 2) before hctr_finalize_weights", mode);
+        }
+        c->mode = mode;
         c->split = mode == 1;
         return HCTR_OK;
+    });
+}
+
+int hctr_set_guard(hctr_ctx* c, double rel, double abs_tol) {
+    return guard(c, [&]() -> int {
+        if (!c) return HCTR_ERR_ARG;
+        if (!(rel >= 0.0) || !(abs_tol >= 0.0)) return fail(c, HCTR_ERR_ARG, "guard tolerances must be >= 0");
+        c->guard_rel = rel;
+        c->guard_abs = abs_tol;
+        return HCTR_OK;
+    });
+}
+
+int hctr_last_guard(hctr_ctx* c, int64_t* lines, int64_t* flagged, uint8_t* flags, float* min_margin, float* scale,
+                    int64_t cap) {
+    return guard(c, [&]() -> int {
+        if (!c) return HCTR_ERR_ARG;
+        const int64_t n = (int64_t)c->g_flag.size();
+        int64_t nf = 0;
+        for (uint8_t f : c->g_flag) nf += f ? 1 : 0;
+        if (lines) *lines = n;
+        if (flagged) *flagged = nf;
+        const int64_t m = n < cap ? n : (cap < 0 ? 0 : cap);
+        if (flags && m) memcpy(flags, c->g_flag.data(), (size_t)m);
+        if (min_margin && m) memcpy(min_margin, c->g_margin.data(), (size_t)m * 4);
+        if (scale && m) memcpy(scale, c->g_scale.data(), (size_t)m * 4);
+        return HCTR_OK;
+    });
+}
+
+int hctr_lines_per_pass(hctr_ctx* c, int B, int W, int f16x3) {
+    return guard(c, [&]() -> int {
+        if (!c) return HCTR_ERR_ARG;
+        if (B < 1 || W < 1) return fail(c, HCTR_ERR_ARG, "bad batch shape B=%d W=%d", B, W);
+        return sub_batch(c, B, W, f16x3 != 0);
     });
 }
 
@@ -995,34 +1164,53 @@ int hctr_forward_logits(hctr_ctx* c, const void* img, int img_dtype, int img_on_
         if (B == 0) return HCTR_OK;
         HIP_TRY(c, hipSetDevice(c->device));
         const int C = c->num_classes;
-        const int nbmax = sub_batch(c, B, W);
+        const bool guarded = c->mode == 2;
+        SplitScope scope(c);
         prof_reset(c);
+        guard_clear(c);
         float* dev_out = out_wbc;
         std::vector<void*> tmp;
         PoolGuard tmp_guard{tmp};
-        if (!out_on_device) {
-            int r = dev_alloc(c, tmp, &dev_out, (size_t)B * W * C, false);
-            if (r != HCTR_OK) { free_pool(tmp); return r; }
-        }
+        if (!out_on_device) TRY(dev_alloc(c, tmp, &dev_out, (size_t)B * W * C, false));
+        std::vector<float> gbuf(guarded ? (size_t)2 * B : 0);
+        // one pass: the lines `lines[0..nb)` -> their rows of the [W][B][C] output
+        auto pass = [&](const int* lines, int nb, bool guard_pass, float* guard_dst) -> int {
+            TRY(ensure_workspace(c, nb, W, ws_need(c, HEAD_LOGITS, guard_pass)));
+            TRY(stage_input(c, img, img_dtype, img_on_device, widths, lines, nb, W));
+            TRY(run_forward(c, img_dtype == HCTR_F32, widths != nullptr, HEAD_LOGITS, guard_pass));
+            for (int i = 0; i < nb;) {             // [nb*W][cpad] -> out[t][line][C], one launch per run of consecutive lines
+                int j = i + 1;
+                while (j < nb && lines[j] == lines[j - 1] + 1) ++j;
+                HIP_TRY(c, launch_logits_to_wbc(c->ws.logits + (size_t)i * W * c->cpad, c->cpad, j - i, W, C, dev_out, B,
+                                                lines[i], c->stream));
+                i = j;
+            }
+            if (guard_pass)
+                HIP_TRY(c, hipMemcpyAsync(guard_dst, c->ws.line_guard, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
+            return HCTR_OK;
+        };
+        std::vector<int> all((size_t)B);
+        for (int b = 0; b < B; ++b) all[(size_t)b] = b;
         int rc = HCTR_OK;
-        for (int b0 = 0; b0 < B && rc == HCTR_OK; b0 += nbmax) {
-            const int nb = std::min(nbmax, B - b0);
-            rc = ensure_workspace(c, nb, W, ws_need(c, HEAD_LOGITS));
-            if (rc == HCTR_OK) rc = stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W);
-            if (rc == HCTR_OK) rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr);
-            if (rc == HCTR_OK) {
-                // [nb*W][cpad] -> out[t][b0+b][C] with full-batch row stride
-                hipError_t e = launch_logits_to_wbc(c->ws.logits, c->cpad, nb, W, C, dev_out, B, b0, c->stream);
-                if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "logits_to_wbc: %s", hipGetErrorString(e));
+        const int nbmax = sub_batch(c, B, W, c->split);
+        for (int b0 = 0; b0 < B && rc == HCTR_OK; b0 += nbmax)
+            rc = pass(all.data() + b0, std::min(nbmax, B - b0), guarded, guarded ? gbuf.data() + 2 * (size_t)b0 : nullptr);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
+        if (rc == HCTR_OK && guarded) {
+            const std::vector<int> flagged = guard_decide(c, gbuf, B);
+            if (!flagged.empty()) {               // the uncertain lines once more, in f16x3, into the same output rows
+                c->split = true;
+                const int nf = (int)flagged.size(), nb3 = sub_batch(c, nf, W, true);
+                for (int o = 0; o < nf && rc == HCTR_OK; o += nb3) rc = pass(flagged.data() + o, std::min(nb3, nf - o), false, nullptr);
             }
         }
         if (rc == HCTR_OK && !out_on_device) {
-            hipError_t e = hipMemcpyAsync(out_wbc, dev_out, (size_t)B * W * C * 4, hipMemcpyDeviceToHost, c->stream);
+            e = hipMemcpyAsync(out_wbc, dev_out, (size_t)B * W * C * 4, hipMemcpyDeviceToHost, c->stream);
             if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "D2H logits: %s", hipGetErrorString(e));
         }
-        hipError_t e = hipStreamSynchronize(c->stream);
+        e = hipStreamSynchronize(c->stream);
         if (rc == HCTR_OK && e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
-        free_pool(tmp);
         return rc;
     });
 }
@@ -1035,15 +1223,18 @@ int hctr_greedy(hctr_ctx* c, const void* img, int img_dtype, int img_on_device, 
         if (B == 0) return HCTR_OK;
         HIP_TRY(c, hipSetDevice(c->device));
         const int C = c->num_classes;
-        const int nbmax = sub_batch(c, B, W);
+        const bool guarded = c->mode == 2;
+        SplitScope scope(c);
         prof_reset(c);
-        // every pass queues async copies into the caller's buffers: on a failure the stream is still drained
-        // before returning, so nothing is in flight into (or out of) caller memory after an error
-        int rc = HCTR_OK;
-        auto pass = [&](int b0, int nb) -> int {
-            TRY(ensure_workspace(c, nb, W, ws_need(c, c->fuse_argmax ? HEAD_ARGMAX : HEAD_LOGITS)));
-            TRY(stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W));
-            TRY(run_forward(c, img_dtype == HCTR_F32, widths != nullptr, c->fuse_argmax ? HEAD_ARGMAX : HEAD_LOGITS));
+        guard_clear(c);
+        std::vector<float> gbuf(guarded ? (size_t)2 * B : 0);
+        const HeadMode hm = c->fuse_argmax ? HEAD_ARGMAX : HEAD_LOGITS;
+        // every pass queues async copies into host buffers: on a failure the stream is still drained before
+        // returning, so nothing is in flight into (or out of) caller memory after an error
+        auto pass = [&](const int* lines, int nb, bool guard_pass, int32_t* lab_dst, int32_t* len_dst, float* guard_dst) -> int {
+            TRY(ensure_workspace(c, nb, W, ws_need(c, hm, guard_pass)));
+            TRY(stage_input(c, img, img_dtype, img_on_device, widths, lines, nb, W));
+            TRY(run_forward(c, img_dtype == HCTR_F32, widths != nullptr, hm, guard_pass));
             Workspace& ws = c->ws;
             Prof pf(c);
             if (!c->fuse_argmax) {
@@ -1054,14 +1245,42 @@ int hctr_greedy(hctr_ctx* c, const void* img, int img_dtype, int img_on_device, 
             pf.begin("ctc_collapse");
             HIP_TRY(c, launch_ctc_collapse(ws.colidx, nb, W, C, ws.labels, ws.lengths, c->stream));
             pf.end();
-            HIP_TRY(c, hipMemcpyAsync(labels + (size_t)b0 * W, ws.labels, (size_t)nb * W * 4, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(lengths + b0, ws.lengths, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(lab_dst, ws.labels, (size_t)nb * W * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(len_dst, ws.lengths, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+            if (guard_pass)
+                HIP_TRY(c, hipMemcpyAsync(guard_dst, ws.line_guard, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
             return HCTR_OK;
         };
-        for (int b0 = 0; b0 < B && rc == HCTR_OK; b0 += nbmax) rc = pass(b0, std::min(nbmax, B - b0));
-        const hipError_t es = hipStreamSynchronize(c->stream);
+        std::vector<int> all((size_t)B);
+        for (int b = 0; b < B; ++b) all[(size_t)b] = b;
+        int rc = HCTR_OK;
+        const int nbmax = sub_batch(c, B, W, c->split);
+        for (int b0 = 0; b0 < B && rc == HCTR_OK; b0 += nbmax)
+            rc = pass(all.data() + b0, std::min(nbmax, B - b0), guarded, labels + (size_t)b0 * W, lengths + b0,
+                      guarded ? gbuf.data() + 2 * (size_t)b0 : nullptr);
+        hipError_t es = hipStreamSynchronize(c->stream);
         if (rc == HCTR_OK && es != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(es));
-        return rc;
+        if (rc != HCTR_OK || !guarded) return rc;
+        // guarded precision: the lines the f16 sweep cannot certify run again in f16x3 at the SAME padded width (a line's
+        // result depends on nothing but its own pixels and W), and their labels replace the f16 ones
+        const std::vector<int> flagged = guard_decide(c, gbuf, B);
+        if (flagged.empty()) return HCTR_OK;
+        c->split = true;
+        const int nf = (int)flagged.size(), nb3 = sub_batch(c, nf, W, true);
+        c->h_labels.resize((size_t)nf * W);
+        c->h_lengths.resize((size_t)nf);
+        for (int o = 0; o < nf && rc == HCTR_OK; o += nb3)
+            rc = pass(flagged.data() + o, std::min(nb3, nf - o), false, c->h_labels.data() + (size_t)o * W,
+                      c->h_lengths.data() + o, nullptr);
+        es = hipStreamSynchronize(c->stream);
+        if (rc == HCTR_OK && es != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "stream sync: %s", hipGetErrorString(es));
+        if (rc != HCTR_OK) return rc;
+        for (int i = 0; i < nf; ++i) {
+            const int n = c->h_lengths[(size_t)i];
+            lengths[flagged[(size_t)i]] = n;
+            if (n > 0) memcpy(labels + (size_t)flagged[(size_t)i] * W, c->h_labels.data() + (size_t)i * W, (size_t)n * 4);
+        }
+        return HCTR_OK;
     });
 }
 
@@ -1129,17 +1348,22 @@ int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_d
         }
         if (k > C) return fail(c, HCTR_ERR_ARG, "k=%d exceeds C=%d", k, C);
         const double thresh = std::log(0.001);        // utils/ctc_codec.py:128
-        const int nbmax = from_img ? sub_batch(c, B, W) : B;
+        const bool guarded = from_img && c->mode == 2;
+        SplitScope scope(c);
         prof_reset(c);
-        struct PassOut { int b0, nb; std::vector<int64_t> loff; std::vector<int32_t> ci; std::vector<float> cl; };
+        guard_clear(c);
+        // candidate lists of one pass (lines in pass order); owner[line] = the pass whose lists are current for the line
+        struct PassOut { std::vector<int> lines; std::vector<int64_t> loff; std::vector<int32_t> ci; std::vector<float> cl; };
         std::vector<PassOut> outs;
+        std::vector<int> owner((size_t)B, -1);
         std::vector<int32_t> counts((size_t)W * B, 0);
         std::vector<int32_t> h_idx, h_cnt;
         std::vector<float> h_lp, h_bl;
+        std::vector<float> gbuf(guarded ? (size_t)2 * B : 0);
         std::vector<void*>& pool = c->beam_allocs;
-        int rc = HCTR_OK;
-        for (int b0 = 0; b0 < B && rc == HCTR_OK; b0 += nbmax) {
-            const int nb = std::min(nbmax, B - b0);
+        // one pass over the lines `lines[0..nb)`: forward (or the caller's logits), log-softmax + top-k (+ lists), results
+        // scattered to the lines' (t, line) rows of the host outputs
+        auto run_pass = [&](const int* lines, int nb, bool guard_pass, float* guard_dst) -> int {
             const int64_t rows = (int64_t)nb * W;
             free_pool(pool);
             const float* rowsrc = nullptr;
@@ -1147,84 +1371,74 @@ int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_d
             // fused front end (default): the logits are never stored; the head GEMM runs twice with reducing epilogues
             // (kernels.h ConvArgs). Not for k beyond the part count / kBeamMaxK, and a pass in which some row needed
             // more than kBeamCap list slots (near-uniform logits) is redone through the stored-logits kernels.
-            bool fused = from_img && c->fuse_beam && k <= kBeamMaxK && k <= c->cpad / 128;
+            bool fused = from_img && c->fuse_beam && k <= kBeamMaxK && k <= head_parts(c);
             if (from_img) {
-                rc = ensure_workspace(c, nb, W, ws_need(c, fused ? HEAD_BEAM : HEAD_LOGITS));
-                if (rc == HCTR_OK) rc = stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W);
-                if (rc == HCTR_OK) rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr, fused ? HEAD_BEAM : HEAD_LOGITS);
+                const HeadMode hm = fused ? HEAD_BEAM : HEAD_LOGITS;
+                TRY(ensure_workspace(c, nb, W, ws_need(c, hm, guard_pass)));
+                TRY(stage_input(c, img, img_dtype, img_on_device, widths, lines, nb, W));
+                TRY(run_forward(c, img_dtype == HCTR_F32, widths != nullptr, hm, guard_pass));
+                if (guard_pass)
+                    HIP_TRY(c, hipMemcpyAsync(guard_dst, c->ws.line_guard, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
                 rowsrc = c->ws.logits; ld = c->cpad;
             } else {
                 float *up = nullptr, *rowsbuf = nullptr;
                 const float* dev = logits_wbc;
                 if (!logits_on_device) {
-                    rc = dev_alloc(c, pool, &up, (size_t)rows * C, false);
-                    if (rc == HCTR_OK) {
-                        hipError_t e = hipMemcpyAsync(up, logits_wbc, (size_t)rows * C * 4, hipMemcpyHostToDevice, c->stream);
-                        if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "H2D logits: %s", hipGetErrorString(e));
-                    }
+                    TRY(dev_alloc(c, pool, &up, (size_t)rows * C, false));
+                    HIP_TRY(c, hipMemcpyAsync(up, logits_wbc, (size_t)rows * C * 4, hipMemcpyHostToDevice, c->stream));
                     dev = up;
                 }
-                if (rc == HCTR_OK) rc = dev_alloc(c, pool, &rowsbuf, (size_t)rows * C, false);
-                if (rc == HCTR_OK) {
-                    hipError_t e = launch_wbc_to_rows(dev, nb, W, C, rowsbuf, C, c->stream);
-                    if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "wbc_to_rows: %s", hipGetErrorString(e));
-                }
+                TRY(dev_alloc(c, pool, &rowsbuf, (size_t)rows * C, false));
+                HIP_TRY(c, launch_wbc_to_rows(dev, nb, W, C, rowsbuf, C, c->stream));
                 rowsrc = rowsbuf; ld = C;
             }
             int32_t *d_idx = nullptr, *d_cnt = nullptr;
             float *d_lp = nullptr, *d_bl = nullptr, *d_st = nullptr;
-            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_idx, (size_t)rows * k, false);
-            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_lp, (size_t)rows * k, false);
-            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_bl, (size_t)rows, false);
-            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_st, (size_t)rows * 2, false);
-            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_cnt, (size_t)rows, false);
-            if (rc != HCTR_OK) break;
-            hipError_t e = hipSuccess;
+            TRY(dev_alloc(c, pool, &d_idx, (size_t)rows * k, false));
+            TRY(dev_alloc(c, pool, &d_lp, (size_t)rows * k, false));
+            TRY(dev_alloc(c, pool, &d_bl, (size_t)rows, false));
+            TRY(dev_alloc(c, pool, &d_st, (size_t)rows * 2, false));
+            TRY(dev_alloc(c, pool, &d_cnt, (size_t)rows, false));
             if (fused) {
-                rc = beam_finish(c, k, want_candidates != 0, thresh, d_idx, d_lp, d_bl, d_st, d_cnt);
+                TRY(beam_finish(c, k, want_candidates != 0, thresh, d_idx, d_lp, d_bl, d_st, d_cnt));
                 int32_t ovf = 0;
-                if (rc == HCTR_OK) {
-                    e = hipMemcpyAsync(&ovf, c->ws.overflow, 4, hipMemcpyDeviceToHost, c->stream);
-                    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-                    if (e != hipSuccess) rc = fail(c, HCTR_ERR_HIP, "beam overflow flag: %s", hipGetErrorString(e));
-                }
-                if (rc != HCTR_OK) break;
+                HIP_TRY(c, hipMemcpyAsync(&ovf, c->ws.overflow, 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
                 if (ovf) {                       // redo this pass with stored logits (re-staged: carving may move the arena)
                     fused = false;
                     ++c->beam_fallbacks;
-                    rc = ensure_workspace(c, nb, W, ws_need(c, HEAD_LOGITS));
-                    if (rc == HCTR_OK) rc = stage_input(c, img, img_dtype, img_on_device, widths, b0, nb, B, W);
-                    if (rc == HCTR_OK) rc = run_forward(c, img_dtype == HCTR_F32, widths != nullptr, HEAD_LOGITS);
-                    if (rc != HCTR_OK) break;
+                    TRY(ensure_workspace(c, nb, W, ws_need(c, HEAD_LOGITS)));
+                    TRY(stage_input(c, img, img_dtype, img_on_device, widths, lines, nb, W));
+                    TRY(run_forward(c, img_dtype == HCTR_F32, widths != nullptr, HEAD_LOGITS));
                     rowsrc = c->ws.logits;
                 }
             }
             if (!fused) {
                 Prof pf(c);
                 pf.begin("row_topk");
-                e = launch_row_topk(rowsrc, ld, nb, W, C, k, thresh, d_idx, d_lp, d_bl, d_st, d_cnt, c->stream);
+                const hipError_t e = launch_row_topk(rowsrc, ld, nb, W, C, k, thresh, d_idx, d_lp, d_bl, d_st, d_cnt, c->stream);
                 pf.end();
+                if (e != hipSuccess) return fail(c, HCTR_ERR_HIP, "row_topk: %s (C=%d)", hipGetErrorString(e), C);
             }
-            if (e != hipSuccess) { rc = fail(c, HCTR_ERR_HIP, "row_topk: %s (C=%d)", hipGetErrorString(e), C); break; }
             h_idx.resize((size_t)rows * k); h_lp.resize((size_t)rows * k); h_bl.resize(rows); h_cnt.resize(rows);
-            e = hipMemcpyAsync(h_idx.data(), d_idx, (size_t)rows * k * 4, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(h_lp.data(), d_lp, (size_t)rows * k * 4, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(h_bl.data(), d_bl, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) { rc = fail(c, HCTR_ERR_HIP, "beam D2H: %s", hipGetErrorString(e)); break; }
+            HIP_TRY(c, hipMemcpyAsync(h_idx.data(), d_idx, (size_t)rows * k * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(h_lp.data(), d_lp, (size_t)rows * k * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(h_bl.data(), d_bl, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
             for (int t = 0; t < W; ++t)
                 for (int b = 0; b < nb; ++b) {
-                    const size_t src = (size_t)t * nb + b, dst = (size_t)t * B + b0 + b;
+                    const size_t src = (size_t)t * nb + b, dst = (size_t)t * B + lines[b];
                     memcpy(topk_idx + dst * k, h_idx.data() + src * k, (size_t)k * 4);
                     memcpy(topk_logp + dst * k, h_lp.data() + src * k, (size_t)k * 4);
                     blank_logp[dst] = h_bl[src];
                     counts[dst] = h_cnt[src];
                 }
-            if (!want_candidates) continue;
+            if (!want_candidates) return HCTR_OK;
             outs.emplace_back();
             PassOut& po = outs.back();
-            po.b0 = b0; po.nb = nb;
+            po.lines.assign(lines, lines + nb);
+            for (int b = 0; b < nb; ++b) owner[(size_t)lines[b]] = (int)outs.size() - 1;
             po.loff.resize(rows + 1);
             int64_t tot = 0;
             for (int64_t r = 0; r < rows; ++r) { po.loff[r] = tot; tot += h_cnt[r]; }
@@ -1233,19 +1447,35 @@ int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_d
             int64_t* d_off = nullptr;
             int32_t* d_ci = nullptr;
             float* d_cl = nullptr;
-            rc = dev_alloc(c, pool, &d_off, (size_t)rows + 1, false);
-            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_ci, (size_t)std::max<int64_t>(tot, 1), false);
-            if (rc == HCTR_OK) rc = dev_alloc(c, pool, &d_cl, (size_t)std::max<int64_t>(tot, 1), false);
-            if (rc != HCTR_OK) break;
-            e = hipMemcpyAsync(d_off, po.loff.data(), (size_t)(rows + 1) * 8, hipMemcpyHostToDevice, c->stream);
-            if (e == hipSuccess)
-                e = fused ? launch_beam_candidates(c->ws.emit_cnt, c->ws.emit_list, kBeamCap, d_st, nb, W, thresh, d_off, d_ci,
-                                                   d_cl, c->stream)
-                          : launch_row_candidates(rowsrc, ld, nb, W, C, thresh, d_st, d_off, d_ci, d_cl, c->stream);
-            if (e == hipSuccess && tot) e = hipMemcpyAsync(po.ci.data(), d_ci, (size_t)tot * 4, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess && tot) e = hipMemcpyAsync(po.cl.data(), d_cl, (size_t)tot * 4, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) { rc = fail(c, HCTR_ERR_HIP, "row_candidates: %s", hipGetErrorString(e)); break; }
+            TRY(dev_alloc(c, pool, &d_off, (size_t)rows + 1, false));
+            TRY(dev_alloc(c, pool, &d_ci, (size_t)std::max<int64_t>(tot, 1), false));
+            TRY(dev_alloc(c, pool, &d_cl, (size_t)std::max<int64_t>(tot, 1), false));
+            HIP_TRY(c, hipMemcpyAsync(d_off, po.loff.data(), (size_t)(rows + 1) * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, fused ? launch_beam_candidates(c->ws.emit_cnt, c->ws.emit_list, kBeamCap, d_st, nb, W, thresh, d_off, d_ci,
+                                                      d_cl, c->stream)
+                             : launch_row_candidates(rowsrc, ld, nb, W, C, thresh, d_st, d_off, d_ci, d_cl, c->stream));
+            if (tot) {
+                HIP_TRY(c, hipMemcpyAsync(po.ci.data(), d_ci, (size_t)tot * 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(po.cl.data(), d_cl, (size_t)tot * 4, hipMemcpyDeviceToHost, c->stream));
+            }
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            return HCTR_OK;
+        };
+        std::vector<int> all((size_t)B);
+        for (int b = 0; b < B; ++b) all[(size_t)b] = b;
+        int rc = HCTR_OK;
+        const int nbmax = from_img ? sub_batch(c, B, W, c->split) : B;
+        for (int b0 = 0; b0 < B && rc == HCTR_OK; b0 += nbmax)
+            rc = run_pass(all.data() + b0, std::min(nbmax, B - b0), guarded, guarded ? gbuf.data() + 2 * (size_t)b0 : nullptr);
+        if (rc == HCTR_OK && guarded) {
+            // guarded precision: lines with a column the f16 sweep cannot certify (same criterion as hctr_greedy) once
+            // more in f16x3; their rows of every output are replaced
+            const std::vector<int> flagged = guard_decide(c, gbuf, B);
+            if (!flagged.empty()) {
+                c->split = true;
+                const int nf = (int)flagged.size(), nb3 = sub_batch(c, nf, W, true);
+                for (int o = 0; o < nf && rc == HCTR_OK; o += nb3) rc = run_pass(flagged.data() + o, std::min(nb3, nf - o), false, nullptr);
+            }
         }
         (void)hipStreamSynchronize(c->stream);
         free_pool(pool);
@@ -1255,16 +1485,20 @@ int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_d
         for (int64_t r = 0; r < (int64_t)W * B; ++r) { c->cand_off[r] = tot; tot += counts[r]; }
         c->cand_off[(size_t)W * B] = tot;
         c->cand_idx.resize(tot); c->cand_logp.resize(tot);
-        for (const PassOut& po : outs)
+        for (size_t pi = 0; pi < outs.size(); ++pi) {
+            const PassOut& po = outs[pi];
+            const int nb = (int)po.lines.size();
             for (int t = 0; t < W; ++t)
-                for (int b = 0; b < po.nb; ++b) {
-                    const size_t src = (size_t)t * po.nb + b, dst = (size_t)t * B + po.b0 + b;
+                for (int b = 0; b < nb; ++b) {
+                    if (owner[(size_t)po.lines[(size_t)b]] != (int)pi) continue;      // a later (f16x3) pass re-did this line
+                    const size_t src = (size_t)t * nb + b, dst = (size_t)t * B + po.lines[(size_t)b];
                     const int64_t n = po.loff[src + 1] - po.loff[src];
                     if (n) {
                         memcpy(c->cand_idx.data() + c->cand_off[dst], po.ci.data() + po.loff[src], (size_t)n * 4);
                         memcpy(c->cand_logp.data() + c->cand_off[dst], po.cl.data() + po.loff[src], (size_t)n * 4);
                     }
                 }
+        }
         if (num_candidates) *num_candidates = tot;
         return HCTR_OK;
     });
@@ -1437,7 +1671,7 @@ int64_t hctr_debug_activation(hctr_ctx* c, const char* name, float* out, int64_t
         if (Hout) *Hout = H;
         if (!out || cap < total) return total;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        const int m = c->chm();                        // [hi | lo | hi] planes in f16x3 mode: report hi + lo
+        const int m = ws.split ? 3 : 1;                // [hi | lo | hi] planes in f16x3 mode: report hi + lo
         const int64_t elems = head ? (int64_t)ws.B * ws.W * kFeat * m : act_elems(ws.B, H, ws.Wa, C * m);
         std::vector<half_t> host((size_t)elems);
         HIP_TRY(c, hipMemcpy(host.data(), p, (size_t)elems * sizeof(half_t), hipMemcpyDeviceToHost));

@@ -50,7 +50,10 @@ int load_rccl() {
             h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (h) break;
         }
-    if (!h) return comm_fail(HCTR_ERR_STATE, std::string("librccl not found: ") + (dlerror() ? dlerror() : ""));
+    if (!h) {
+        const char* de = dlerror();                             // (a second call would return NULL: it clears the error)
+        return comm_fail(HCTR_ERR_STATE, std::string("librccl not found: ") + (de ? de : ""));
+    }
     Rccl r;
     r.handle = h;
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
@@ -138,20 +141,26 @@ int hctr_gather_labels(hctr_comm* c, const int32_t* labels, const int32_t* lengt
                        int lines_per_rank, int cap, int32_t* out_labels, int32_t* out_lengths) {
     COMM_GUARD(
         if (!c) return comm_fail(HCTR_ERR_ARG, "comm is NULL");
-        if (n_local < 0 || lines_per_rank < n_local || cap < 0 || row_stride < cap)
-            return comm_fail(HCTR_ERR_ARG, "bad shape (n_local <= lines_per_rank, cap <= row_stride)");
-        if (n_local > 0 && (!labels || !lengths)) return comm_fail(HCTR_ERR_ARG, "labels/lengths is NULL");
+        // Arguments every rank passes identically (lines_per_rank, cap) decide the collective's size: if THEY are bad no
+        // rank can enter it, so return at once. Anything wrong with this rank's own data (a NULL pointer, a sequence
+        // longer than cap, a failed copy) must not leave the other ranks waiting in the all-gather: this rank still takes
+        // part, with the sentinel -1 in the length slot of its first row, and EVERY rank returns HCTR_ERR_ARG.
+        if (lines_per_rank < 1 || cap < 0) return comm_fail(HCTR_ERR_ARG, "bad shape (lines_per_rank >= 1, cap >= 0)");
         if (!out_labels || !out_lengths) return comm_fail(HCTR_ERR_ARG, "out_labels/out_lengths is NULL");
         if (hipSetDevice(c->device) != hipSuccess) return comm_fail(HCTR_ERR_HIP, "hipSetDevice failed");
+        std::string local_err;
+        if (n_local < 0 || n_local > lines_per_rank || row_stride < cap) local_err = "bad shape (0 <= n_local <= lines_per_rank, cap <= row_stride)";
+        else if (n_local > 0 && (!labels || !lengths)) local_err = "labels/lengths is NULL";
         // packed like dist.pack_labels: [lines_per_rank][1 + cap] int32, column 0 = length, zero padded
         const size_t row = (size_t)1 + cap, per = (size_t)lines_per_rank * row;
         std::vector<int32_t> send(per, 0);
-        for (int i = 0; i < n_local; ++i) {
+        for (int i = 0; local_err.empty() && i < n_local; ++i) {
             const int n = lengths[i];
-            if (n < 0 || n > cap) return comm_fail(HCTR_ERR_ARG, "a label sequence is longer than cap");
+            if (n < 0 || n > cap) { local_err = "a label sequence is longer than cap"; break; }
             send[i * row] = n;
             if (n) memcpy(&send[i * row + 1], labels + (size_t)i * row_stride, (size_t)n * 4);
         }
+        if (!local_err.empty()) send[0] = -1;
         if (c->cap_send < per) {
             if (c->d_send) (void)hipFree(c->d_send);
             c->d_send = nullptr; c->cap_send = 0;
@@ -166,7 +175,11 @@ int hctr_gather_labels(hctr_comm* c, const int32_t* labels, const int32_t* lengt
         }
         std::vector<int32_t> recv(per * c->world);
         hipError_t e = hipMemcpyAsync(c->d_send, send.data(), per * 4, hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) return comm_fail(HCTR_ERR_HIP, std::string("H2D: ") + hipGetErrorString(e));
+        if (e != hipSuccess) {                        // still join the collective (with whatever d_send holds) - see above
+            local_err = std::string("H2D: ") + hipGetErrorString(e);
+            const int32_t bad = -1;
+            (void)hipMemcpy(c->d_send, &bad, 4, hipMemcpyHostToDevice);
+        }
         ncclResult_t r = g_rccl.AllGather(c->d_send, c->d_recv, per, ncclInt32, c->comm, c->stream);
         if (r != ncclSuccess) {
             (void)hipStreamSynchronize(c->stream);
@@ -175,6 +188,10 @@ int hctr_gather_labels(hctr_comm* c, const int32_t* labels, const int32_t* lengt
         e = hipMemcpyAsync(recv.data(), c->d_recv, per * c->world * 4, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return comm_fail(HCTR_ERR_HIP, std::string("D2H: ") + hipGetErrorString(e));
+        if (!local_err.empty()) return comm_fail(HCTR_ERR_ARG, local_err);
+        for (int rk = 0; rk < c->world; ++rk)
+            if (recv[(size_t)rk * per] < 0)
+                return comm_fail(HCTR_ERR_ARG, "rank " + std::to_string(rk) + " reported bad arguments to hctr_gather_labels");
         const size_t total = (size_t)lines_per_rank * c->world;
         for (size_t i = 0; i < total; ++i) {
             const int n = recv[i * row];

@@ -40,6 +40,11 @@ struct ConvArgs {
     // amax_val/amax_idx[(nt*WN + wn) * M + m]; launch_argmax_partials picks the first maximum per row.
     float* amax_val;
     int32_t* amax_idx;
+    // guarded precision (hctr_set_precision mode 2): when amax_val2 is set the same epilogue also writes, per
+    // (part, row), the RUNNER-UP value of the part (amax_val2, -inf for a one-class part) and the part's largest
+    // |logit| (amax_abs); launch_argmax_partials turns them into the row's top-1/top-2 margin and max |logit|.
+    float* amax_val2;
+    float* amax_abs;
     // linear mode, fused beam front end (log_softmax + top-k + p > 0.001 lists, utils/ctc_codec.py:65,127-128,144,186)
     // without storing the logits. PASS 1 = the argmax partials above plus, when psum is set, per (part, row) the sum of
     // expf(v - part max) and the logit of class 0 per row. launch_beam_thresholds turns those into per-row
@@ -92,8 +97,16 @@ inline int conv_tile_couts(ConvTile t) {
 
 hipError_t launch_conv(const ConvArgs& a, ConvTile tile, int taps, bool linear_f32, hipStream_t s);
 constexpr int kLinearWN = 2;          // wave columns of both linear-mode tiles (partials per n-tile)
-// rows [P][M] of (value, class) partials -> idx[M]: first maximum, 0 for an all-(-inf)/NaN row
-hipError_t launch_argmax_partials(const float* val, const int32_t* cls, int P, int64_t M, int32_t* idx, hipStream_t s);
+// rows [P][M] of (value, class) partials -> idx[M]: first maximum, 0 for an all-(-inf)/NaN row (idx may be NULL).
+// With val2 / absp (the guard partials, see ConvArgs) also margin[M] = top-1 minus top-2 logit of the row over all
+// classes (0 for an exact tie, NaN when a NaN is involved) and rowabs[M] = max |logit| of the row.
+hipError_t launch_argmax_partials(const float* val, const int32_t* cls, int P, int64_t M, int32_t* idx, hipStream_t s,
+                                  const float* val2 = nullptr, const float* absp = nullptr, float* margin = nullptr,
+                                  float* rowabs = nullptr);
+// the same two per-row figures from stored logits rows [M][ld] (hctr_forward_logits in guarded mode)
+hipError_t launch_row_guard(const float* logits, int64_t ld, int64_t M, int C, float* margin, float* rowabs, hipStream_t s);
+// per line b: out[b][0] = min over its W columns of margin (NaN if any is NaN), out[b][1] = max of rowabs
+hipError_t launch_line_guard(const float* margin, const float* rowabs, int B, int W, float* out, hipStream_t s);
 size_t conv_lds_bytes(ConvTile tile);
 
 // NormalizePAD + conv0_1 + bn0_1 + ReLU computed into the LDS halo of conv0_2's tile, then conv0_2 + bn0_2 + ReLU +

@@ -152,30 +152,58 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
     if (LINEAR && a.amax_idx != nullptr) {
         // fused greedy argmax: classes rise with (j, i) for a lane and with q, wn, nt beyond it, so a strict
         // '>' keeps the first maximum inside a lane and the (value, class) merge keeps it across lanes.
+        // Guarded precision (a.amax_val2 set): the part's runner-up value and largest |logit| ride along.
         static_assert(!LINEAR || WN == kLinearWN, "partials per n-tile");
         const int64_t part = (int64_t)((n0 / BN) * WN + wn) * a.M;
+        const bool guard = a.amax_val2 != nullptr;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            float bv = -INFINITY;
+            float bv = -INFINITY, sv = -INFINITY, av = 0.f;
             int bi = 0x7fffffff;
+            if (!guard) {
 #pragma unroll
-            for (int j = 0; j < JT; ++j)
+                for (int j = 0; j < JT; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int cls = cw0 + co(j) + i;
-                    const float v = acc[j][n][i];
-                    if (cls < a.Cout && np_gt(v, bv)) { bv = v; bi = cls; }
-                }
+                    for (int i = 0; i < 4; ++i) {
+                        const int cls = cw0 + co(j) + i;
+                        const float v = acc[j][n][i];
+                        if (cls < a.Cout && np_gt(v, bv)) { bv = v; bi = cls; }
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int cls = cw0 + co(j) + i;
+                        const float v = acc[j][n][i];
+                        if (cls < a.Cout) {
+                            av = fmaxf(av, fabsf(v));
+                            if (np_gt(v, bv)) { sv = bv; bv = v; bi = cls; }
+                            else if (np_gt(v, sv)) sv = v;
+                        }
+                    }
+            }
 #pragma unroll
             for (int off = 16; off <= 32; off <<= 1) {
                 const float ov = __shfl_xor(bv, off);
                 const int oi = __shfl_xor(bi, off);
-                if (np_gt(ov, bv) || (np_eq(ov, bv) && oi < bi)) { bv = ov; bi = oi; }
+                const bool wins = np_gt(ov, bv) || (np_eq(ov, bv) && oi < bi);
+                if (guard) {                       // runner-up of the union: the loser's best or the winner's second
+                    const float osv = __shfl_xor(sv, off);
+                    const float lose = wins ? bv : ov, keep2 = wins ? osv : sv;
+                    sv = np_gt(lose, keep2) ? lose : keep2;
+                    av = fmaxf(av, __shfl_xor(av, off));
+                }
+                if (wins) { bv = ov; bi = oi; }
             }
             const int64_t m = (int64_t)mt * BM + wm * 64 + n * 16 + c;
             if (q == 0 && m < a.M) {
                 a.amax_val[part + m] = bv;
                 a.amax_idx[part + m] = bi;
+                if (guard) {
+                    a.amax_val2[part + m] = sv;
+                    a.amax_abs[part + m] = av;
+                }
             }
             if (a.psum != nullptr) {
                 // beam front end, PASS 1: sum of expf(v - part max) per (part, row), and the logit of class 0
@@ -2007,24 +2035,116 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
     }
 }
 
-// second stage of the fused head argmax: thread per row over the P = ntiles * WN partials (class ranges rise with p)
+// second stage of the fused head argmax: thread per row over the P = ntiles * WN partials (class ranges rise with p).
+// Guarded precision: with the runner-up / |logit| partials it also forms the row's top-1/top-2 margin over ALL classes
+// (the runner-up of the row is the second largest of the union of every part's best two) and its largest |logit|.
 __global__ __launch_bounds__(256) void argmax_partials_kernel(const float* __restrict__ val, const int32_t* __restrict__ cls,
-                                                              int P, int64_t M, int32_t* __restrict__ idx) {
+                                                              int P, int64_t M, int32_t* __restrict__ idx,
+                                                              const float* __restrict__ val2, const float* __restrict__ absp,
+                                                              float* __restrict__ margin, float* __restrict__ rowabs) {
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
-    float bv = -INFINITY;
+    float bv = -INFINITY, sv = -INFINITY, av = 0.f;
     int bi = 0x7fffffff;
     for (int p = 0; p < P; ++p) {
         const float v = val[(int64_t)p * M + m];
         const int i = cls[(int64_t)p * M + m];
-        if (np_gt(v, bv) || (np_eq(v, bv) && i < bi)) { bv = v; bi = i; }
+        const bool wins = np_gt(v, bv) || (np_eq(v, bv) && i < bi);
+        if (val2 != nullptr) {
+            const float v2 = val2[(int64_t)p * M + m];
+            const float lose = wins ? bv : v, keep2 = wins ? v2 : sv;
+            sv = np_gt(lose, keep2) ? lose : keep2;
+            av = fmaxf(av, absp[(int64_t)p * M + m]);
+        }
+        if (wins) { bv = v; bi = i; }
     }
-    idx[m] = (bi == 0x7fffffff) ? 0 : bi;
+    if (idx != nullptr) idx[m] = (bi == 0x7fffffff) ? 0 : bi;
+    if (val2 != nullptr) {
+        margin[m] = bv - sv;
+        rowabs[m] = av;
+    }
 }
 
-hipError_t launch_argmax_partials(const float* val, const int32_t* cls, int P, int64_t M, int32_t* idx, hipStream_t s) {
+hipError_t launch_argmax_partials(const float* val, const int32_t* cls, int P, int64_t M, int32_t* idx, hipStream_t s,
+                                  const float* val2, const float* absp, float* margin, float* rowabs) {
     if (M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(argmax_partials_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, val, cls, P, M, idx);
+    if (val2 != nullptr && (absp == nullptr || margin == nullptr || rowabs == nullptr)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(argmax_partials_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, val, cls, P, M, idx, val2,
+                       absp, margin, rowabs);
+    return hipGetLastError();
+}
+
+// Guarded precision on stored logits (hctr_forward_logits): one wave per row, top-1/top-2 margin (exact ties give 0,
+// a NaN gives NaN) and largest |logit|. Same figures as the fused partials produce.
+__global__ __launch_bounds__(256) void row_guard_kernel(const float* __restrict__ x, int64_t ld, int64_t M, int C,
+                                                        float* __restrict__ margin, float* __restrict__ rowabs) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* p = x + row * ld;
+    float bv = -INFINITY, sv = -INFINITY, av = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float v = p[c];
+        av = fmaxf(av, fabsf(v));
+        if (np_gt(v, bv)) { sv = bv; bv = v; }
+        else if (np_gt(v, sv)) sv = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(bv, off), osv = __shfl_xor(sv, off);
+        const bool wins = np_gt(ov, bv);
+        const float lose = wins ? bv : ov, keep2 = wins ? osv : sv;
+        sv = np_gt(lose, keep2) ? lose : keep2;
+        if (wins) bv = ov;
+        av = fmaxf(av, __shfl_xor(av, off));
+    }
+    if (lane == 0) {
+        margin[row] = bv - sv;
+        rowabs[row] = av;
+    }
+}
+
+hipError_t launch_row_guard(const float* logits, int64_t ld, int64_t M, int C, float* margin, float* rowabs, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(row_guard_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, logits, ld, M, C, margin, rowabs);
+    return hipGetLastError();
+}
+
+// one block per line: the smallest top-2 margin over the line's columns (pad columns included: the reference decodes
+// them too, utils/ctc_codec.py:75 over test.py:170-186's padded batch) and the line's largest |logit|
+__global__ __launch_bounds__(256) void line_guard_kernel(const float* __restrict__ margin, const float* __restrict__ rowabs,
+                                                         int W, float* __restrict__ out) {
+    __shared__ float smin[4], smax[4];
+    __shared__ int sbad[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float mn = INFINITY, mx = 0.f;
+    int bad = 0;
+    for (int t = threadIdx.x; t < W; t += 256) {
+        const float mg = margin[(int64_t)b * W + t];
+        bad |= (mg != mg) ? 1 : 0;
+        mn = fminf(mn, mg);
+        mx = fmaxf(mx, rowabs[(int64_t)b * W + t]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off));
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+        bad |= __shfl_xor(bad, off);
+    }
+    if (lane == 0) { smin[wv] = mn; smax[wv] = mx; sbad[wv] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+        mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+        bad = sbad[0] | sbad[1] | sbad[2] | sbad[3];
+        out[2 * b] = bad ? NAN : mn;
+        out[2 * b + 1] = mx;
+    }
+}
+
+hipError_t launch_line_guard(const float* margin, const float* rowabs, int B, int W, float* out, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(line_guard_kernel, dim3(B), dim3(256), 0, s, margin, rowabs, W, out);
     return hipGetLastError();
 }
 

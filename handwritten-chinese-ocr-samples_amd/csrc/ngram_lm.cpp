@@ -94,7 +94,10 @@ const char* hctr_ngram_last_error(void) { return g_ngram_error.c_str(); }
 static int ngram_load_impl(const char* arpa_path, hctr_ngram** out);
 
 int hctr_ngram_load(const char* arpa_path, hctr_ngram** out) {
-    if (!arpa_path || !out) return HCTR_ERR_ARG;
+    if (!arpa_path || !out) {
+        try { g_ngram_error = "hctr_ngram_load: arpa_path / out is NULL"; } catch (...) {}
+        return HCTR_ERR_ARG;
+    }
     *out = nullptr;
     try {
         return ngram_load_impl(arpa_path, out);

@@ -17,6 +17,7 @@ import numpy as np
 from . import _lib
 
 IncompatibleKeys = collections.namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])
+_PRECISIONS = {"f16": 0, "f16x3": 1, "auto": 2}
 
 
 def _is_torch(x):
@@ -25,10 +26,14 @@ def _is_torch(x):
 
 class hctr_model(object):
     def __init__(self, num_classes=7375, precision="f16"):
-        """``precision``: "f16" (default; fp16 storage/MFMA, fp32 accumulate) or "f16x3" (hi+lo split
-        pairs, ~3x the work, fp32-grade logits) - an engine option, not part of the reference surface."""
-        if precision not in ("f16", "f16x3"):
-            raise ValueError("precision must be 'f16' or 'f16x3'")
+        """``precision`` (an engine option, not part of the reference surface): "f16" (default; fp16 storage/MFMA, fp32
+        accumulate), "f16x3" (hi+lo split pairs, ~3x the work, fp32-grade logits) or "auto" (guarded: every line in f16,
+        and the lines with a column whose top-1/top-2 logit margin is within twice the f16 logit tolerance once more in
+        f16x3 - the f16x3 mode's text wherever f16 cannot certify its own, f16 speed on peaky logits; see
+        include/hctr_hip.h ``hctr_set_precision``). A model built with "auto" holds both weight sets and can be switched
+        between all three modes afterwards (``set_precision``)."""
+        if precision not in _PRECISIONS:
+            raise ValueError("precision must be 'f16', 'f16x3' or 'auto'")
         self.precision = precision
         # attributes of the reference class (models/handwritten_ctr_model.py:159-164)
         self.img_height = 128
@@ -75,7 +80,7 @@ class hctr_model(object):
         lib = _lib.load()
         ctx = ctypes.c_void_p()
         _lib.check(lib.hctr_create(ctypes.byref(ctx), device, int(self.noutput)))
-        _lib.check(lib.hctr_set_precision(ctx, 1 if self.precision == "f16x3" else 0), ctx)
+        _lib.check(lib.hctr_set_precision(ctx, _PRECISIONS[self.precision]), ctx)
         self._ctx, self._device = ctx, device
         if self._pending_sd is not None:
             sd, self._pending_sd = self._pending_sd, None
@@ -232,6 +237,47 @@ class hctr_model(object):
         x, dt, on_dev, B, W = self._img_args(input)
         wd = self._widths(widths, B)
         return beam_frontend_call(ctx, x, dt, on_dev, wd, None, 0, B, W, int(self.noutput), k, want_candidates)
+
+    # -- precision mode ---------------------------------------------------------------------------
+    def set_precision(self, precision):
+        """Switch the mode of a loaded model among those whose weight set is resident (all three for a model built
+        with precision="auto"; raises RuntimeError otherwise)."""
+        if precision not in _PRECISIONS:
+            raise ValueError("precision must be 'f16', 'f16x3' or 'auto'")
+        if self._ctx is not None:
+            _lib.check(_lib.load().hctr_set_precision(self._ctx, _PRECISIONS[precision]), self._ctx)
+            self._active_precision = precision
+        else:
+            self.precision = precision
+        return self
+
+    def set_guard(self, rel=0.01, abs=0.05):
+        """Criterion of the "auto" mode: a line is run again in f16x3 unless every column's top-1/top-2 logit margin
+        exceeds 2 * (rel * max|logit of the line| + abs)."""
+        _lib.check(_lib.load().hctr_set_guard(self._require_ctx(), float(rel), float(abs)), self._ctx)
+        return self
+
+    def last_guard(self):
+        """Figures of the last call in "auto" mode: dict(lines, flagged, flags[uint8], min_margin[float32],
+        scale[float32]) per line of that call's batch (empty arrays after a call in another mode)."""
+        ctx = self._require_ctx()
+        lib = _lib.load()
+        n, nf = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(lib.hctr_last_guard(ctx, ctypes.byref(n), ctypes.byref(nf), None, None, None, 0), ctx)
+        flags = np.zeros((n.value,), np.uint8)
+        mg = np.zeros((n.value,), np.float32)
+        sc = np.zeros((n.value,), np.float32)
+        _lib.check(lib.hctr_last_guard(ctx, None, None, _lib.ptr(flags), _lib.ptr(mg), _lib.ptr(sc), n.value), ctx)
+        return {"lines": int(n.value), "flagged": int(nf.value), "flags": flags, "min_margin": mg, "scale": sc}
+
+    def lines_per_pass(self, B, W, f16x3=None):
+        """Lines per internal pass of a batch of B lines of width W (HCTR_MAX_COLS pixel columns, a third in f16x3)."""
+        if f16x3 is None:
+            f16x3 = getattr(self, "_active_precision", self.precision) == "f16x3"
+        n = _lib.load().hctr_lines_per_pass(self._require_ctx(), int(B), int(W), int(bool(f16x3)))
+        if n < 0:
+            _lib.check(n, self._ctx)
+        return n
 
     # -- introspection --------------------------------------------------------------------------
     def set_profiling(self, enabled=True):

@@ -60,13 +60,34 @@ int hctr_load_tensor(hctr_ctx* ctx, const char* key, const void* host_ptr,
                      const int64_t* shape, int ndim, int dtype);
 int hctr_finalize_weights(hctr_ctx* ctx);
 
-/* ---- precision mode (call before hctr_finalize_weights) ------------------------------------------
+/* ---- precision mode ----------------------------------------------------------------------------------
  * 0 = f16 (default): fp16 storage and MFMA inputs, fp32 accumulation - the 10-bit mantissa of the TF32
  *     mode the reference enables on its GPUs (main.py:37-41).
  * 1 = f16x3: every activation and weight is carried as a hi + lo fp16 pair and each product is formed
  *     as w_hi*x_hi + w_hi*x_lo + w_lo*x_hi in fp32 (about 3x the matrix work and memory); logits then
- *     agree with the fp32 CPU reference to ~1e-4 relative, for parity triage and near-tie-free decoding. */
+ *     agree with the fp32 CPU reference to ~1e-5 relative: its argmax / text is the reference's wherever
+ *     two fp32 summation orders agree.
+ * 2 = guarded ("auto"): every line runs in f16 and the head's fused epilogue also yields, per pixel column,
+ *     the margin between the largest and second largest logit. A line is CERTAIN when every one of its
+ *     columns (pad columns included - the reference decodes them too, utils/ctc_codec.py:75 over the padded
+ *     batch of test.py:170-186) has margin > 2 * (rel * max|logit of the line| + abs): no error within the
+ *     f16 logit tolerance rel * scale + abs can then change an argmax. Every other line is run again in
+ *     f16x3 at the same padded width (a line's result depends only on its own pixels and that width) and
+ *     its results replace the f16 ones - in hctr_greedy, hctr_forward_logits and hctr_beam_frontend alike.
+ *     Text is then the f16x3 mode's wherever f16 cannot be trusted, at f16 speed for lines with peaky
+ *     logits. Both weight sets stay resident (about 0.42 GB).
+ * Before hctr_finalize_weights the mode decides which weight set(s) are built (0: f16, 1: f16x3, 2: both);
+ * afterwards it may still be changed among the modes whose set(s) are resident (a context finalized in
+ * mode 2 serves all three).
+ * hctr_set_guard: rel / abs of mode 2's criterion (defaults 0.01 / 0.05 = the f16 logit tolerance the parity
+ *     suite asserts, tests/test_gpu_parity.py LOGIT_RTOL / LOGIT_ATOL).
+ * hctr_last_guard: figures of the last mode-2 call, per line of its batch: flags[i] = 1 if line i was
+ *     run again in f16x3, min_margin[i] = its smallest column margin, scale[i] = its largest |logit| (f16 sweep).
+ *     Any output pointer may be NULL; at most cap entries are written. */
 int hctr_set_precision(hctr_ctx* ctx, int mode);
+int hctr_set_guard(hctr_ctx* ctx, double rel, double abs_tol);
+int hctr_last_guard(hctr_ctx* ctx, int64_t* lines, int64_t* flagged, uint8_t* flags, float* min_margin,
+                    float* scale, int64_t cap);
 
 /* ---- forward: replaces hctr_model.forward --------------------------------------------------
  * models/handwritten_ctr_model.py:171-178 (trunk :115-153). Input: a batch of B line images of
@@ -124,8 +145,11 @@ int hctr_log_softmax(hctr_ctx* ctx, const float* logits_wbc, int on_device, int 
  *   score_cb: called once per time step with n sentences (label ids of prefix+suffix, CSR in
  *             ids/offs); must fill scores[n]. Replaces ngram.score(' '.join(chars), eos=False)
  *             / transformer.score(batch, char_based=True).
- *   next_cb:  optional (use_tfm_pred): for n beam prefixes fill out_ids[n][k] with the LM's k most
- *             likely next labels (utils/ctc_codec.py:216-227); NULL disables.
+ *   next_cb:  optional (use_tfm_pred): for n beam prefixes fill out_ids[n][k] with the LM's next labels
+ *             (utils/ctc_codec.py:216-227; k = search_depth on the first call of a step). The reference chains
+ *             whatever list the LM returns (:225-226): pad a shorter list with the <unknown> id C-1 (skipped, :238-239)
+ *             and return 0; if some list is LONGER than k return the number of slots needed (> k) and the search
+ *             calls again with that k. Negative = failure (propagated). NULL disables.
  * builtin_lm: 0 = callbacks, 1 = zero LM, 2 = toy hashed bigram over code points (needs
  *             label_codepoints[C]), 3 = ARPA n-gram (needs ngram + label_words[C]); built-ins make
  *             the multi-threaded path callback-free.
@@ -216,6 +240,9 @@ const char* hctr_comm_last_error(void);
  * Returns the number of layers recorded (or a negative status). Enabled by hctr_set_profiling. */
 int hctr_set_profiling(hctr_ctx* ctx, int enabled);
 int hctr_last_profile(hctr_ctx* ctx, char* names_buf, int cap, float* ms, int max_n);
+/* Lines per internal pass for a batch of B lines of width W (a batch beyond HCTR_MAX_COLS pixel columns - a third
+ * of that in f16x3 - runs in balanced passes; hctr_last_profile adds the passes' entries of one name up). */
+int hctr_lines_per_pass(hctr_ctx* ctx, int B, int W, int f16x3);
 /* Diagnostic build of the 3x3 conv kernel: with layer != NULL, arms time-stamping of that layer's
  * workgroups (a separate kernel instance; results of the forward are unchanged) for up to cap_wgs
  * workgroups and returns 0. With layer == NULL copies the last forward's stamps to out[n][16]

@@ -99,7 +99,7 @@ class FakeTransformer(object):
     """Deterministic stand-in for the reference's transformer LM object (utils/transformer_infer.py:41-76 as used at
     utils/ctc_codec.py:215-227,269-274): ``score(list[str], char_based=True) -> list[float]`` and
     ``next_k_words(list[str], k=, char_based=True) -> list[list[str]]``. ``ragged`` makes next_k_words return FEWER
-    than k words for some prefixes (the reference chains whatever comes back)."""
+    than k words for some prefixes, ``ragged="long"`` MORE than k for some (the reference chains whatever comes back)."""
 
     def __init__(self, chars, ragged=False):
         self.chars = list(chars)
@@ -113,7 +113,10 @@ class FakeTransformer(object):
         out = []
         for p in prefixes:
             base = (ord(p[-1]) if p else 0) + len(p)
-            n = k if not self.ragged else max(0, k - (base % 4))
+            if self.ragged == "long":
+                n = k + (base % 3)
+            else:
+                n = k if not self.ragged else max(0, k - (base % 4))
             out.append([self.chars[(base + 3 * j) % len(self.chars)] for j in range(n)])
         return out
 
@@ -125,5 +128,6 @@ TFM_CASES = [
     ("score_and_pred", 9, 36, 2, 16, "mixed", True, True, False),
     ("pred_ragged", 11, 40, 2, 24, "flat", False, True, True),
     ("both_ragged_peaky", 12, 48, 3, 40, "peaky", True, True, True),
+    ("pred_long_lists", 13, 40, 2, 24, "flat", False, True, "long"),
 ]
 TFM_SETTINGS = dict(search_depth=6, beam_size=5, lm_panelty=0.8, len_bonus=4.8)

@@ -127,7 +127,8 @@ def test_host_beam_search_transformer_hooks(pkg):
     """use_tfm_score / use_tfm_pred duck-typed hooks (utils/ctc_codec.py:215-227,269-274): the engine's host search
     AND the oracle codec, each driven by the same fake transformer object, must reproduce the strings the REAL
     reference codec produced with it (tests/golden/codec_tfm.json, made by make_golden_tfm.py), including
-    next_k_words lists shorter than k."""
+    next_k_words lists shorter than k and LONGER than k (the reference chains whatever it gets, :225-226; the C ABI's
+    callback then asks for more slots and is called again)."""
     from oracle import ctc_ref
     with open(os.path.join(GOLDEN, "codec_tfm.json")) as f:
         gold = json.load(f)
