@@ -16,13 +16,18 @@ def shard_range(n_lines, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def pack_labels(label_lists, cap):
-    """[n][1 + cap] int32: column 0 = length, then the labels (zero padded)."""
+def pack_labels(label_lists, cap, strict=True):
+    """[n][1 + cap] int32: column 0 = length, then the labels (zero padded). A sequence longer than ``cap`` raises;
+    with ``strict=False`` its row gets the length -1 instead (so a rank can still take part in the collective and every
+    reader of the row sees the error)."""
     out = np.zeros((len(label_lists), 1 + cap), dtype=np.int32)
     for i, lab in enumerate(label_lists):
         n = len(lab)
         if n > cap:
-            raise ValueError("label sequence longer than cap")
+            if strict:
+                raise ValueError("label sequence longer than cap")
+            out[i, 0] = -1
+            continue
         out[i, 0] = n
         out[i, 1:1 + n] = lab
     return out
@@ -37,14 +42,22 @@ def gather_labels(label_lists, n_lines, cap, device=None, group=None):
 
     Each rank passes the label arrays of its ``shard_range`` lines. All ranks send a buffer padded
     to the largest shard (ceil(n_lines / world)) so the collective is a plain ``gather``.
-    Returns the full list on rank 0, None elsewhere."""
+    Returns the full list on rank 0, None elsewhere.
+
+    ``cap`` = labels per line in the packed buffer. Callers pass the padded width W: a collapsed sequence can be as
+    long as W (alternating labels), and random-init weights really emit ~W/2 labels per line (978 of 2000 on
+    BASELINE's synthetic lines), so SURVEY 8e's "Lmax < 128" does not hold for this workload and no smaller constant
+    is safe without a second collective to agree on it. The message stays small (4.1 MB per rank at 512 lines x 2000).
+    A rank whose sequence exceeds ``cap`` still takes part in the gather (length -1 in that row) and raises afterwards;
+    rank 0 raises on seeing the sentinel - nobody is left waiting in the collective."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     per = -(-n_lines // world)
     buf = np.zeros((per, 1 + cap), dtype=np.int32)
-    mine = pack_labels(label_lists, cap)
+    mine = pack_labels(label_lists, cap, strict=False)
     buf[:mine.shape[0]] = mine
+    overflow = bool((mine[:, 0] < 0).any())
     t = torch.from_numpy(buf)
     if device is not None:
         t = t.to(device)
@@ -53,12 +66,17 @@ def gather_labels(label_lists, n_lines, cap, device=None, group=None):
     else:
         outs = None
     dist.gather(t, outs, dst=0, group=group)
+    if overflow:
+        raise ValueError("label sequence longer than cap=%d on rank %d" % (cap, rank))
     if rank != 0:
         return None
     result = []
     for r in range(world):
         lo, hi = shard_range(n_lines, r, world)
-        result.extend(unpack_labels(outs[r].cpu().numpy()[:hi - lo]))
+        rows = outs[r].cpu().numpy()[:hi - lo]
+        if (rows[:, 0] < 0).any():
+            raise ValueError("rank %d reported a label sequence longer than cap=%d" % (r, cap))
+        result.extend(unpack_labels(rows))
     return result
 
 

@@ -417,3 +417,22 @@ def test_state_dict_round_trip_without_gpu(pkg, synth):
     m2 = pkg.hctr_model(C)
     m2.load_state_dict(back)                               # torch tensors are accepted like numpy arrays
     assert np.array_equal(m2.state_dict()["linear.weight"].numpy(), sd["linear.weight"])
+
+
+def test_bench_multi_gpu_launch_fails_loudly_without_gpus():
+    """`python bench.py --gpus 2` starts its own ranks as child processes (torch.distributed.run) and exits with THEIR
+    code: on a machine without a GPU the ranks fail at hctr_create (no CPU fallback), the parent prints no result line
+    and returns non-zero - it neither hangs nor reports a number."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HCTR_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--batch", "2", "--width", "64"], env=env, capture_output=True, text=True, timeout=600)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by tests/test_gpu_parity.py::test_bench_strong_scaling_rehearsal")
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "starting 2 ranks" in r.stderr

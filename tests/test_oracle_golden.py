@@ -174,3 +174,33 @@ def test_trained_checkpoint_fixture_is_peaky(synth):
     _, truth = synth.make_font_lines(64, meta["width"], meta["seed"], with_truth=True)
     edits = sum(ctc_ref.edit_distance(t, synth.font_truth_text(b, meta["width"])) for t, b in zip(meta["greedy"], truth))
     assert edits <= 0.05 * sum(len(t) for t in meta["greedy"])
+
+
+def test_fast_toy_checker_equals_the_plain_oracle_and_the_reference():
+    """bench.py's config-5 checker (oracle.ctc_ref.FastToyCodecRef on the device's top-k: memoised toy-LM prefix sums,
+    search fed with the top-k classes instead of the full log-prob rows) must be the SAME search: on every codec case it
+    reproduces the strings the REAL reference codec produced with the toy-bigram LM (tests/golden/codec_cases.json)."""
+    from scipy.special import log_softmax
+    with open(os.path.join(GOLDEN, "codec_cases.json"), encoding="utf-8") as f:
+        gold = json.load(f)
+    checked = 0
+    for name, seed, w, b, c, style in codec_cases.CODEC_CASES:
+        logits = codec_cases.gen_logits(seed, w, b, c, style)
+        lp = log_softmax(logits, axis=2)
+        for tag, skip, lm, pen, bonus, beam, depth in codec_cases.BEAM_SETTINGS:
+            if skip or lm != "toy":
+                continue
+            oc = ctc_ref.FastToyCodecRef(codec_cases.vocab(c))
+            oc.use_beam_search, oc.use_tfm_pred, oc.skip_search = True, False, False
+            oc.lm_panelty, oc.len_bonus, oc.beam_size, oc.search_depth = pen, bonus, beam, depth
+            k = min(depth, c)
+            oc.search_depth = k
+            topk = np.flip(np.argsort(lp, axis=2), axis=2)[:, :, :k]
+            tlp = np.take_along_axis(lp, topk, axis=2).astype(np.float32)
+            try:
+                got = oc.beam_full_from_topk(topk, tlp)
+            except IndexError:
+                got = "IndexError"
+            assert got == gold[name][tag], (name, tag)
+            checked += 1
+    assert checked >= 10

@@ -37,4 +37,18 @@ for name, seed, widths in (("b3w67u", 22, [67, 50, 33]), ("b2w96", 23, [96, 96])
         if list(t[keep]) != list(labels[b]):
             print("greedy mismatch on line", b)
             sys.exit(2)
+# fused beam front end (head GEMM twice with reducing epilogues) against the stored-logits kernels on this variant's own
+# logits: identical top-k, log-probs and candidate lists (covers the part count of the 128x128 head tile, HCTR_BIG_TILES=0)
+import importlib  # noqa: E402
+mm = importlib.import_module(hctr_amd.package.__name__ + ".model")
+imgs = synth.make_line_images(3, 120, 5)
+fe = model.beam_frontend(imgs, k=10, want_candidates=True)
+lg = np.ascontiguousarray(model(imgs))
+ref = mm.beam_frontend_call(model._ctx, None, 0, 0, None, lg, 0, 3, 120, C, 10, True)
+n = int(fe["cand_off"][-1])
+same = all(np.array_equal(fe[k], ref[k]) for k in ("topk_idx", "topk_logp", "blank_logp", "cand_off")) and n > 0 and \
+    np.array_equal(fe["cand_idx"][:n], ref["cand_idx"][:n]) and np.array_equal(fe["cand_logp"][:n], ref["cand_logp"][:n])
+print("beam front end fused == stored logits:", same, flush=True)
+if not same:
+    sys.exit(3)
 print("ok", worst)
