@@ -611,7 +611,7 @@ def run_c5(args, hctr_amd, model, dev, host, steps, warmup, pool):
         torch.cuda.synchronize(dev)
         return out, (time.perf_counter() - t0) / steps
     res = {"workload": "BASELINE configs[4]: B=256 x 1x128x2000, cbs_full beam 10 / depth 10, toy-bigram LM, device "
-                       "log-softmax+top-k, C++ host prefix search on %d threads, f16" % len(os.sched_getaffinity(0)),
+                       "log-softmax+top-k, C++ host prefix search on %d threads, f16" % min(64, hctr_amd.package._lib.usable_cpus()),
            "unit": "lines/s", "steps": steps, "warmup": warmup}
     if not args.no_pipeline:
         out, dt = timed(lambda: pipe.recognize_beam(model, codec, dev_imgs, chunk=args.chunk))

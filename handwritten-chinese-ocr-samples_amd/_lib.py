@@ -154,6 +154,7 @@ SIGNATURES = [
     ("hctr_set_guard", _I, [_VP, ctypes.c_double, ctypes.c_double]),
     ("hctr_last_guard", _I, [_VP, c_i64p, c_i64p, _VP, _VP, _VP, _I64]),
     ("hctr_lines_per_pass", _I, [_VP, _I, _I, _I]),
+    ("hctr_workspace_stats", _I, [_VP, c_i64p, c_i64p, c_i64p]),
     ("hctr_forward_logits", _I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I]),
     ("hctr_greedy", _I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _VP]),
     ("hctr_decode_greedy_logits", _I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP]),
@@ -242,6 +243,21 @@ def check(rc, ctx=None):
     msg = load().hctr_last_error(ctx)
     msg = msg.decode("utf-8", "replace") if msg else ""
     raise _EXC.get(rc, RuntimeError)("hctr engine error %d: %s" % (rc, msg))
+
+
+def usable_cpus():
+    """CPUs this process can really keep busy: its affinity mask, capped by the cgroup CPU quota when there is one
+    (a container with cpu.max = 16 CPUs on a 256-thread host is throttled by the scheduler if 64 threads spin)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            with open(path) as f:
+                q, per = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
 
 
 def ptr(a):

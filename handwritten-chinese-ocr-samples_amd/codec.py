@@ -101,7 +101,7 @@ class ctc_codec(object):
         self.skip_search = False
         self.use_beam_search = False
 
-        self.num_threads = 0          # host beam-search threads (0 = all cores, max 64); built-in LMs only
+        self.num_threads = 0          # host beam-search threads (0 = the CPUs this process may use, max 64); built-in LMs only
         self._ctx = None
         self._own_ctx = False
         self._model = None            # attach(): resolve the engine context through the model at call time
@@ -220,7 +220,7 @@ class ctc_codec(object):
         params.search_depth = min(int(self.search_depth), k)
         params.lm_panelty = float(self.lm_panelty)
         params.len_bonus = float(self.len_bonus)
-        params.num_threads = int(self.num_threads) or min(64, len(__import__("os").sched_getaffinity(0)))
+        params.num_threads = int(self.num_threads) or min(64, _lib.usable_cpus())
         params.user = None
         chars = self.characters
         err = []

@@ -80,6 +80,11 @@ struct Workspace {
     int32_t* emit_list = nullptr;   // [B*W][kBeamCap][2]
     double* esum = nullptr;         // [P][B*W]
     int32_t* overflow = nullptr;    // [1]
+    int32_t* bm_idx = nullptr;      // [B*W][kBeamMaxK] outputs of the fused front end (rows r = t*B + b), before the D2H
+    float* bm_lp = nullptr;         // [B*W][kBeamMaxK]
+    float* bm_bl = nullptr;         // [B*W]
+    float* bm_st = nullptr;         // [B*W][2]
+    int32_t* bm_cnt = nullptr;      // [B*W]
     int32_t* tile_ctrs = nullptr;   // [64 launches][8 XCDs] tile queues of the persistent conv variant (HCTR_PERSIST=2)
     // guarded precision (WS_GUARD): runner-up / |logit| partials of the fused head, per-column and per-line figures
     float* amax_val2 = nullptr;     // [P][B*W]
@@ -144,6 +149,12 @@ struct hctr_ctx {
     // line| + guard_abs - the tolerance the parity suite asserts) are run again in f16x3 at the same padded width.
     int mode = 0;
     bool split = false;
+    // HCTR_X3_MASK (diagnostic, tests/diag_precision_attribution.py): which classes of rounding points the f16x3 mode
+    // carries as hi + lo; a cleared bit rounds that class to one fp16 value like the f16 mode. 1 = conv weights,
+    // 2 = conv1 outputs of the blocks, 4 = block outputs (the residual stream), 8 = stem and stage-conv outputs,
+    // 16 = head input and head weights. Default 31 = the f16x3 mode proper.
+    int x3_mask = 31;
+    int out_class = 8;               // rounding-point class of the conv being launched (set by run_block / run_forward)
     double guard_rel = 0.01, guard_abs = 0.05;
     // guard figures of the last call in mode 2 (per line of that call's batch)
     std::vector<float> g_margin, g_scale;
@@ -152,6 +163,8 @@ struct hctr_ctx {
     std::vector<std::vector<int32_t>> h_widths;          // gathered widths of this call's passes (source of async copies:
                                                          // kept until the next call; every call drains the stream first)
     std::vector<int32_t> h_labels, h_lengths;            // labels of a re-run pass before they are scattered
+    char* pin = nullptr;                                 // pinned host staging of the beam front end's D2H copies
+    size_t pin_cap = 0;
     int chm() const { return split ? 3 : 1; }      // channel multiplier of activation buffers
     bool fuse_se = true;
     std::string stamp_layer;         // hctr_debug_stamps: layer whose workgroups are time-stamped (diagnostic)
@@ -312,7 +325,7 @@ int build_conv(hctr_ctx* c, const std::string& ck, const std::string& bk, int ci
                     row[ci] = hi;
                     if (c->split) {
                         row[cin + ci] = hi;
-                        row[2 * cin + ci] = (half_t)(float)(v - (double)(float)hi);
+                        row[2 * cin + ci] = (c->x3_mask & 1) ? (half_t)(float)(v - (double)(float)hi) : (half_t)0.f;
                     }
                 }
         }
@@ -394,7 +407,7 @@ int build_head(hctr_ctx* c, WeightSet& ws) {
                         half_t* r = dst + h * 1536;
                         r[ch] = hi;
                         r[512 + ch] = hi;
-                        r[1024 + ch] = (half_t)(v - (float)hi);
+                        r[1024 + ch] = (c->x3_mask & 16) ? (half_t)(v - (float)hi) : (half_t)0.f;
                     }
                 }
         }
@@ -485,6 +498,11 @@ int ensure_workspace(hctr_ctx* c, int B, int W, int features = 0) {
         A(&ws.emit_cnt, cols);
         A(&ws.esum, P * cols);
         A(&ws.overflow, (size_t)1);
+        A(&ws.bm_idx, cols * kBeamMaxK);
+        A(&ws.bm_lp, cols * kBeamMaxK);
+        A(&ws.bm_bl, cols);
+        A(&ws.bm_st, 2 * cols);
+        A(&ws.bm_cnt, cols);
         A(&ws.emit_list, cols * kBeamCap * 2);
     }
     bool fresh = false;
@@ -585,6 +603,7 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
     a.x = in.p; a.w = cw.w; a.bias = cw.bias; a.y = out; a.se_part = se_part;
     a.se_scale = se_scale; a.resid = resid;
     a.split = c->split ? 1 : 0;
+    a.drop_lo = (c->split && !(c->x3_mask & c->out_class)) ? 1 : 0;
     const int m = c->chm();                        // cw.cin already counts the tripled input channels
     a.H = in.H; a.W = ws.W; a.Cin = cw.cin; a.Cout = cw.cout; a.CoutPad = cw.coutPad;
     const ConvTile tile = pick_tile(c, cw, in.H);
@@ -657,12 +676,15 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
     const bool fuse_ds = bw.has_ds && c->fuse_ds && (c->fuse_se || c->split) && bw.ds.cin % kBK == 0 &&
                          pick_tile(c, bw.conv2, H) == TILE_HALO4;
     if (bw.has_ds && !fuse_ds) {
+        c->out_class = 4;
         TRY(run_conv(c, pf, (name + ".downsample").c_str(), bw.ds, in, r, H, false, false, nullptr, false));
         res = r;
     }
     if (c->fuse_se || c->split) {
         const int tiles1 = tiles_of(bw.conv1);
+        c->out_class = 2;
         TRY(run_conv(c, pf, (name + ".conv1").c_str(), bw.conv1, in, t, H, true, false, ws.se_part, false));
+        c->out_class = 4;
         pf.begin((name + ".se_stats").c_str());
         HIP_TRY(c, launch_se_border(t, ws.B, H, ws.W, ws.Wa, planes, c->split, ws.se_part, tiles1, ws.se_border, c->stream));
         pf.end();
@@ -679,7 +701,9 @@ int run_block(hctr_ctx* c, Prof& pf, const std::string& name, const BlockW& bw, 
                          nullptr, false, ws.se_scale, res));
         return HCTR_OK;
     }
+    c->out_class = 2;
     TRY(run_conv(c, pf, (name + ".conv1").c_str(), bw.conv1, in, t, H, true, false, nullptr, false));
+    c->out_class = 4;
     TRY(run_conv(c, pf, (name + ".conv2").c_str(), bw.conv2, ActDesc{t, H, planes}, o, H, false, false,
                  ws.se_part, false));
     const int tiles = tiles_of(bw.conv2);
@@ -734,6 +758,7 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths, HeadMode mode = HEAD
         HIP_TRY(c, hipMemsetAsync(ws.tile_ctrs, 0, 64 * 8 * 4, c->stream));
         c->conv_seq = 0;
     }
+    c->out_class = 8;
     if (c->fuse_stem && !c->split) {
         // conv0_1's output (16 kB per pixel column) never reaches HBM: it is computed into conv0_2's LDS halo
         TRY(run_conv(c, pf, "stem+conv0_2+pool", wt.conv0_2, ActDesc{nullptr, 128, 64}, ws.x[1], 64, true, true, nullptr,
@@ -741,7 +766,7 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths, HeadMode mode = HEAD
     } else {
         pf.begin("stem.conv0_1");
         HIP_TRY(c, launch_stem(ws.img, img_f32, have_widths ? ws.widths : nullptr, wt.stem_w, wt.stem_b, ws.s0, ws.B,
-                               ws.W, ws.Wa, c->split, c->stream));
+                               ws.W, ws.Wa, c->split ? ((c->x3_mask & 8) ? 1 : 2) : 0, c->stream));
         pf.end();
         TRY(run_conv(c, pf, "conv0_2+pool", wt.conv0_2, ActDesc{ws.s0, 128, 64}, ws.x[1], 64, true, true, nullptr, false));
     }
@@ -764,6 +789,7 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths, HeadMode mode = HEAD
         }
         char nm[32];
         snprintf(nm, sizeof(nm), "conv%d+pool", s);
+        c->out_class = s < 4 ? 8 : 16;            // (conv4+pool writes the head input)
         if (s < 4)
             TRY(run_conv(c, pf, nm, wt.stage_conv[s - 1], cur, ws.x[s + 1], H / 2, true, true, nullptr, false));
         else
@@ -969,6 +995,7 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
         if (const char* fb = getenv("HCTR_FUSE_BEAM")) c->fuse_beam = atoi(fb) != 0;
         if (const char* fs2 = getenv("HCTR_FUSE_STEM")) c->fuse_stem = atoi(fs2) != 0;
         if (const char* ps = getenv("HCTR_PERSIST")) c->persist_dynamic = atoi(ps) == 2;
+        if (const char* xm = getenv("HCTR_X3_MASK")) c->x3_mask = atoi(xm) & 31;
         if (const char* mc = getenv("HCTR_MAX_COLS")) {
             const long long v = atoll(mc);
             if (v > 0) c->max_cols = v;
@@ -983,6 +1010,7 @@ void hctr_destroy(hctr_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->arena) (void)hipFree(c->arena);
+    if (c->pin) (void)hipHostFree(c->pin);
     free_pool(c->wallocs);
     free_pool(c->beam_allocs);
     if (c->stamp_buf) (void)hipFree(c->stamp_buf);
@@ -1111,6 +1139,14 @@ int hctr_last_guard(hctr_ctx* c, int64_t* lines, int64_t* flagged, uint8_t* flag
         if (scale && m) memcpy(scale, c->g_scale.data(), (size_t)m * 4);
         return HCTR_OK;
     });
+}
+
+int hctr_workspace_stats(hctr_ctx* c, int64_t* arena_bytes, int64_t* arena_allocations, int64_t* recarves) {
+    if (!c) return HCTR_ERR_ARG;
+    if (arena_bytes) *arena_bytes = (int64_t)c->arena_cap;
+    if (arena_allocations) *arena_allocations = c->arena_reallocs;
+    if (recarves) *recarves = c->ws_recarves;
+    return HCTR_OK;
 }
 
 int hctr_lines_per_pass(hctr_ctx* c, int B, int W, int f16x3) {
@@ -1357,8 +1393,6 @@ int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_d
         std::vector<PassOut> outs;
         std::vector<int> owner((size_t)B, -1);
         std::vector<int32_t> counts((size_t)W * B, 0);
-        std::vector<int32_t> h_idx, h_cnt;
-        std::vector<float> h_lp, h_bl;
         std::vector<float> gbuf(guarded ? (size_t)2 * B : 0);
         std::vector<void*>& pool = c->beam_allocs;
         // one pass over the lines `lines[0..nb)`: forward (or the caller's logits), log-softmax + top-k (+ lists), results
@@ -1392,14 +1426,20 @@ int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_d
                 HIP_TRY(c, launch_wbc_to_rows(dev, nb, W, C, rowsbuf, C, c->stream));
                 rowsrc = rowsbuf; ld = C;
             }
+            // device outputs (rows r = t*nb + b): inside the arena on the fused path (no allocation per pass)
             int32_t *d_idx = nullptr, *d_cnt = nullptr;
             float *d_lp = nullptr, *d_bl = nullptr, *d_st = nullptr;
-            TRY(dev_alloc(c, pool, &d_idx, (size_t)rows * k, false));
-            TRY(dev_alloc(c, pool, &d_lp, (size_t)rows * k, false));
-            TRY(dev_alloc(c, pool, &d_bl, (size_t)rows, false));
-            TRY(dev_alloc(c, pool, &d_st, (size_t)rows * 2, false));
-            TRY(dev_alloc(c, pool, &d_cnt, (size_t)rows, false));
+            auto own_outputs = [&]() -> int {
+                TRY(dev_alloc(c, pool, &d_idx, (size_t)rows * k, false));
+                TRY(dev_alloc(c, pool, &d_lp, (size_t)rows * k, false));
+                TRY(dev_alloc(c, pool, &d_bl, (size_t)rows, false));
+                TRY(dev_alloc(c, pool, &d_st, (size_t)rows * 2, false));
+                TRY(dev_alloc(c, pool, &d_cnt, (size_t)rows, false));
+                return HCTR_OK;
+            };
             if (fused) {
+                const Workspace& w0 = c->ws;
+                d_idx = w0.bm_idx; d_lp = w0.bm_lp; d_bl = w0.bm_bl; d_st = w0.bm_st; d_cnt = w0.bm_cnt;
                 TRY(beam_finish(c, k, want_candidates != 0, thresh, d_idx, d_lp, d_bl, d_st, d_cnt));
                 int32_t ovf = 0;
                 HIP_TRY(c, hipMemcpyAsync(&ovf, c->ws.overflow, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1411,7 +1451,10 @@ int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_d
                     TRY(stage_input(c, img, img_dtype, img_on_device, widths, lines, nb, W));
                     TRY(run_forward(c, img_dtype == HCTR_F32, widths != nullptr, HEAD_LOGITS));
                     rowsrc = c->ws.logits;
+                    TRY(own_outputs());
                 }
+            } else {
+                TRY(own_outputs());
             }
             if (!fused) {
                 Prof pf(c);
@@ -1420,19 +1463,34 @@ int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_d
                 pf.end();
                 if (e != hipSuccess) return fail(c, HCTR_ERR_HIP, "row_topk: %s (C=%d)", hipGetErrorString(e), C);
             }
-            h_idx.resize((size_t)rows * k); h_lp.resize((size_t)rows * k); h_bl.resize(rows); h_cnt.resize(rows);
-            HIP_TRY(c, hipMemcpyAsync(h_idx.data(), d_idx, (size_t)rows * k * 4, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(h_lp.data(), d_lp, (size_t)rows * k * 4, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(h_bl.data(), d_bl, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream));
+            // D2H through a pinned staging buffer (grown on demand): a pageable destination is copied in small staged pieces
+            const size_t nk = (size_t)rows * k, need_pin = (2 * nk + 2 * (size_t)rows) * 4;
+            if (c->pin_cap < need_pin) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (c->pin) (void)hipHostFree(c->pin);
+                c->pin = nullptr; c->pin_cap = 0;
+                void* hp = nullptr;
+                if (hipHostMalloc(&hp, need_pin + need_pin / 8, hipHostMallocDefault) != hipSuccess)
+                    return fail(c, HCTR_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed", need_pin);
+                c->pin = (char*)hp; c->pin_cap = need_pin + need_pin / 8;
+            }
+            int32_t* p_idx = (int32_t*)c->pin;
+            float* p_lp = (float*)(p_idx + nk);
+            float* p_bl = p_lp + nk;
+            int32_t* p_cnt = (int32_t*)(p_bl + rows);
+            HIP_TRY(c, hipMemcpyAsync(p_idx, d_idx, nk * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(p_lp, d_lp, nk * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(p_bl, d_bl, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(p_cnt, d_cnt, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const int32_t* h_idx_p = p_idx; const float* h_lp_p = p_lp; const float* h_bl_p = p_bl; const int32_t* h_cnt_p = p_cnt;
             for (int t = 0; t < W; ++t)
                 for (int b = 0; b < nb; ++b) {
                     const size_t src = (size_t)t * nb + b, dst = (size_t)t * B + lines[b];
-                    memcpy(topk_idx + dst * k, h_idx.data() + src * k, (size_t)k * 4);
-                    memcpy(topk_logp + dst * k, h_lp.data() + src * k, (size_t)k * 4);
-                    blank_logp[dst] = h_bl[src];
-                    counts[dst] = h_cnt[src];
+                    memcpy(topk_idx + dst * k, h_idx_p + src * k, (size_t)k * 4);
+                    memcpy(topk_logp + dst * k, h_lp_p + src * k, (size_t)k * 4);
+                    blank_logp[dst] = h_bl_p[src];
+                    counts[dst] = h_cnt_p[src];
                 }
             if (!want_candidates) return HCTR_OK;
             outs.emplace_back();
@@ -1441,7 +1499,7 @@ int hctr_beam_frontend(hctr_ctx* c, const void* img, int img_dtype, int img_on_d
             for (int b = 0; b < nb; ++b) owner[(size_t)lines[b]] = (int)outs.size() - 1;
             po.loff.resize(rows + 1);
             int64_t tot = 0;
-            for (int64_t r = 0; r < rows; ++r) { po.loff[r] = tot; tot += h_cnt[r]; }
+            for (int64_t r = 0; r < rows; ++r) { po.loff[r] = tot; tot += h_cnt_p[r]; }
             po.loff[rows] = tot;
             po.ci.resize(tot); po.cl.resize(tot);
             int64_t* d_off = nullptr;

@@ -68,6 +68,8 @@ struct ConvArgs {
     const float* stem_b;
     int split;              // f16x3 mode: activations are [hi | lo | hi] fp16 planes of Cout channels each
                             // (input side: Cin already counts the tripled channels)
+    int drop_lo;            // f16x3 diagnostic (HCTR_X3_MASK, precision attribution): round this layer's output to ONE fp16
+                            // value like the f16 mode does (the lo plane is written as zeros)
     // fused 1x1 downsample of a block's input (first block of stages 1-3): the halo4 kernel first accumulates
     // ds_w * ds_x (centre tap, ds_cin channels, same H/W/Wa geometry as x), turns it into the residual term and
     // continues with the 3x3 taps; resid must then be NULL and se_scale set. NULL = not used.
@@ -117,6 +119,7 @@ hipError_t launch_stem_conv0_2(const ConvArgs& a, hipStream_t s);
 // > W of every other row (the interior is rewritten by every forward; see engine.cpp ensure_workspace)
 hipError_t launch_zero_borders(half_t* p, int B, int H, int W, int Wa, int C, hipStream_t s);
 
+// split: 0 = fp16 output, 1 = [hi | lo | hi] planes, 2 = planes with the lo plane zero (HCTR_X3_MASK diagnostic)
 hipError_t launch_stem(const void* img, int img_f32, const int32_t* widths_dev, const float* w9,
                        const float* bias, half_t* y, int B, int W, int Wa, int split, hipStream_t s);
 

@@ -399,7 +399,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
                 if (!wvalid) v = 0.f;
                 if (SPLIT) {                        // stored as hi + lo: keep what the two planes add up to
                     const half_t hi = (half_t)v;
-                    v = (float)hi + (float)(half_t)(v - (float)hi);
+                    v = a.drop_lo ? (float)hi : (float)hi + (float)(half_t)(v - (float)hi);      // (drop_lo: lo plane = 0 below)
                 } else {
                     v = (float)(half_t)v;
                 }
@@ -1440,7 +1440,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ img,
             for (int t = 0; t < 9; ++t) sv = fmaf(wt[e][t], win[t / 3][t % 3], sv);
             sv = fmaxf(sv, 0.f);
             o[e] = (half_t)sv;
-            ol[e] = (half_t)(sv - (float)o[e]);
+            ol[e] = split == 2 ? (half_t)0.f : (half_t)(sv - (float)o[e]);
         }
         half_t* dst = y + (((int64_t)b * 130 + h + 1) * Wa + (w + 1)) * cs + cg * 8;
         *(f16x8*)dst = o;

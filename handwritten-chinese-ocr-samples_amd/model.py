@@ -280,6 +280,13 @@ class hctr_model(object):
         return n
 
     # -- introspection --------------------------------------------------------------------------
+    def workspace_stats(self):
+        """dict(arena_bytes, arena_allocations, recarves) of the engine's workspace arena."""
+        a, n, r = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(_lib.load().hctr_workspace_stats(self._require_ctx(), ctypes.byref(a), ctypes.byref(n), ctypes.byref(r)),
+                   self._ctx)
+        return {"arena_bytes": int(a.value), "arena_allocations": int(n.value), "recarves": int(r.value)}
+
     def set_profiling(self, enabled=True):
         _lib.check(_lib.load().hctr_set_profiling(self._require_ctx(), int(enabled)), self._ctx)
 

@@ -240,6 +240,9 @@ const char* hctr_comm_last_error(void);
  * Returns the number of layers recorded (or a negative status). Enabled by hctr_set_profiling. */
 int hctr_set_profiling(hctr_ctx* ctx, int enabled);
 int hctr_last_profile(hctr_ctx* ctx, char* names_buf, int cap, float* ms, int max_n);
+/* Workspace arena of the context: bytes currently allocated, how often it was (re)allocated - it only ever grows, to
+ * the largest layout seen - and how often its layout was re-carved for a new (lines, width, precision) shape. */
+int hctr_workspace_stats(hctr_ctx* ctx, int64_t* arena_bytes, int64_t* arena_allocations, int64_t* recarves);
 /* Lines per internal pass for a batch of B lines of width W (a batch beyond HCTR_MAX_COLS pixel columns - a third
  * of that in f16x3 - runs in balanced passes; hctr_last_profile adds the passes' entries of one name up). */
 int hctr_lines_per_pass(hctr_ctx* ctx, int B, int W, int f16x3);

@@ -1080,3 +1080,61 @@ def test_config3_widths_equal_the_real_reference(pkg, synth):
     m3 = pkg.hctr_model(C, precision="f16x3").cuda(0)
     m3.load_state_dict(synth.make_state_dict(C, seed=0, head="trained"))
     assert cd.labels_to_text(m3.greedy(batch, widths=wd)) == gold["ragged"]["greedy"]
+
+
+def test_config3_full_size_bucketed_batch():
+    """BASELINE configs[2] at FULL size: 512 lines in four equal-width buckets of 128 (widths 800/1600/2400/3200, the
+    buckets beyond HCTR_MAX_COLS run in balanced internal passes). A line's labels must not depend on its batch: lines
+    run alone give the labels they got inside their bucket; two runs are identical; once every bucket shape has been
+    seen the workspace arena is neither re-allocated nor grown."""
+    import importlib
+    from conftest import PKG
+    pkg = importlib.import_module(PKG)
+    synth = pkg.synth
+    C = synth.DEFAULT_VOCAB + 2
+    m = pkg.hctr_model(C).cuda(0)
+    m.load_state_dict(synth.make_state_dict(C, seed=0))
+    buckets = [(w, synth.make_line_images(128, w, 3, line_offset=bi * 128)) for bi, w in enumerate((800, 1600, 2400, 3200))]
+    first = [m.greedy(imgs) for _, imgs in buckets]
+    st0 = m.workspace_stats()
+    second = [m.greedy(imgs) for _, imgs in buckets]
+    st1 = m.workspace_stats()
+    assert st1["arena_allocations"] == st0["arena_allocations"] and st1["arena_bytes"] == st0["arena_bytes"]
+    assert st0["arena_bytes"] < 64 * 2 ** 30
+    for a, b in zip(first, second):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert sum(len(x) for x in first) == 512 and all(len(lab) > 0 for x in first for lab in x)
+    for (w, imgs), labs in zip(buckets, first):
+        assert m.lines_per_pass(128, w) == {800: 128, 1600: 64, 2400: 43, 3200: 32}[w]
+        for i in (0, 42, 43, 127):                          # first / last lines of internal passes, run ALONE
+            alone = m.greedy(imgs[i:i + 1])
+            assert np.array_equal(alone[0], labs[i]), (w, i)
+
+
+def test_config5_full_size_beam_batch():
+    """BASELINE configs[4] at FULL size: 256 lines x 1x128x2000, cbs_full beam 10 / depth 10 with the toy-bigram LM.
+    The pipelined decode (front end of chunk i+1 on the GPU while the host searches chunk i) must equal the two stages
+    back to back on ALL 256 lines, and the six lines of tests/golden/c5_beam_lines.json (strings of the REAL reference's
+    forward + codec) must come out exactly inside the big batch (lines 0-5; trained-like checkpoint)."""
+    import importlib
+    from conftest import PKG
+    pkg = importlib.import_module(PKG)
+    synth = pkg.synth
+    pipe = importlib.import_module(PKG + ".pipeline")
+    with open(os.path.join(GOLDEN, "c5_beam_lines.json"), encoding="utf-8") as f:
+        gold = json.load(f)
+    assert gold["width"] == 2000
+    C = synth.DEFAULT_VOCAB + 2
+    m = pkg.hctr_model(C).cuda(0)
+    m.load_state_dict(synth.make_state_dict(C, seed=0, head="trained"))
+    imgs = np.concatenate([synth.make_font_lines(gold["lines"], 2000, gold["seed"]),
+                           synth.make_font_lines(256 - gold["lines"], 2000, 5)], axis=0)
+    cd = pkg.ctc_codec(synth.characters()).attach(m)
+    cd.use_beam_search, cd.skip_search, cd.use_tfm_pred, cd.use_tfm_score = True, False, False, False
+    cd.lm_panelty, cd.len_bonus, cd.beam_size, cd.search_depth, cd.ngram = 0.8, 4.8, 10, 10, pkg.ToyBigramLM()
+    seq = cd.decode_frontend(m.beam_frontend(imgs, k=10))
+    assert len(seq) == 256 and seq[:gold["lines"]] == gold["full_toy"]
+    for chunk in (32, 48):
+        assert pipe.recognize_beam(m, cd, imgs, chunk=chunk) == seq, chunk
+    # greedy text of the same batch through the fused path, for the six golden lines
+    assert cd.labels_to_text(m.greedy(imgs[:gold["lines"]])) == gold["greedy"]
