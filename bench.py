@@ -217,7 +217,7 @@ def parse_args():
     ap.add_argument("--checkpoint", default="random", choices=["random", "trained"],
                     help="synthetic checkpoint: near-tie-rich random head (default) or the trained-like head")
     ap.add_argument("--no-pipeline", action="store_true", help="c5: run front end and host search back to back")
-    ap.add_argument("--chunk", type=int, default=32, help="c5: lines per pipeline chunk")
+    ap.add_argument("--chunk", type=int, default=64, help="c5: lines per pipeline chunk (the last chunks taper to 16)")
     ap.add_argument("--extra-steps", type=int, default=2, help="timed steps of the configs[2] / configs[4] records")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"],
                     help="c2 (default, the driver's line): B=64 x W=2000 greedy at 1 GPU (+ the c3 / c5 records), configs[3] "
@@ -611,13 +611,14 @@ def run_c5(args, hctr_amd, model, dev, host, steps, warmup, pool):
         torch.cuda.synchronize(dev)
         return out, (time.perf_counter() - t0) / steps
     res = {"workload": "BASELINE configs[4]: B=256 x 1x128x2000, cbs_full beam 10 / depth 10, toy-bigram LM, device "
-                       "log-softmax+top-k, C++ host prefix search on %d threads, f16" % min(64, hctr_amd.package._lib.usable_cpus()),
+                       "log-softmax+top-k, C++ host prefix search on %d threads, f16" % min(64, len(os.sched_getaffinity(0)), 4 * hctr_amd.package._lib.usable_cpus()),
            "unit": "lines/s", "steps": steps, "warmup": warmup}
     if not args.no_pipeline:
         out, dt = timed(lambda: pipe.recognize_beam(model, codec, dev_imgs, chunk=args.chunk))
         res["value"] = round(n_lines / dt, 3)
         res["ms_per_step"] = round(dt * 1e3, 3)
-        res["pipeline"] = "front end of chunk i+1 (GPU) overlaps the host search of chunk i, chunks of %d lines" % args.chunk
+        res["pipeline"] = "front end of chunk i+1 (GPU) overlaps the host search of chunk i; chunks of %s lines" % \
+            [hi - lo for lo, hi in pipe.chunk_schedule(n_lines, args.chunk)]
     # the two stages back to back, timed separately
     t_front, t_search, fe_keep = [0.0], [0.0], [None]
 

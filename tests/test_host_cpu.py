@@ -436,3 +436,15 @@ def test_bench_multi_gpu_launch_fails_loudly_without_gpus():
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "starting 2 ranks" in r.stderr
+
+
+def test_beam_pipeline_chunk_schedule(pkg):
+    """pipeline.chunk_schedule: contiguous cover of the batch, chunks never above the limit, large chunks first and a
+    taper to small ones at the end (nothing overlaps the host search of the last chunk)."""
+    from importlib import import_module
+    pipe = import_module(pkg.__name__ + ".pipeline")
+    for n, c in ((256, 64), (256, 32), (10, 64), (64, 64), (100, 32), (7, 2), (300, 128), (0, 64), (1, 64), (40, 64)):
+        sp = pipe.chunk_schedule(n, c)
+        assert sum(h - l for l, h in sp) == n and all(0 < h - l <= c for l, h in sp)
+        assert all(a[1] == b[0] for a, b in zip(sp, sp[1:])) and (not sp or (sp[0][0] == 0 and sp[-1][1] == n))
+    assert [h - l for l, h in pipe.chunk_schedule(256, 64)] == [64, 64, 64, 32, 16, 16]
