@@ -94,6 +94,7 @@ struct Workspace {
     float* line_guard = nullptr;    // [B][2] = {min margin, max |logit|} per line
     int features = 0;               // WS_* sets carved into this layout
     bool split = false;             // layout of the f16x3 planes (3x the activation channels)
+    bool aliased = false;           // activation buffers shared between the stages (see ensure_workspace)
 };
 
 // optional parts of a workspace layout (carved behind the core buffers, so adding one moves nothing)
@@ -137,6 +138,8 @@ struct hctr_ctx {
     size_t arena_cap = 0;
     int ws_sticky = 0;                  // optional parts this context has needed so far (kept in later layouts)
     int64_t arena_reallocs = 0, ws_recarves = 0;
+    int ws_alias = -1;                  // HCTR_WS_ALIAS: 1 = stages share four activation buffers, 0 = never, -1 = only when
+                                        // the dedicated layout does not fit into the device's free memory
     int64_t max_cols = kDefaultMaxCols;
     bool big_tiles = true;
     int halo_mode = 2;
@@ -437,73 +440,99 @@ inline int head_parts(const hctr_ctx* c) {
 
 int ensure_workspace(hctr_ctx* c, int B, int W, int features = 0) {
     c->ws_sticky |= features;
-    const bool same_shape = c->ws.B == B && c->ws.W == W && c->ws.split == c->split;
+    bool same_shape = c->ws.B == B && c->ws.W == W && c->ws.split == c->split;
     int feat = c->ws_sticky;
     if (c->fuse_stem && !c->split) feat &= ~WS_S0;        // (mode 2 alternates layouts: conv0_1's buffer only where it is used)
     if (same_shape && (c->ws.features & feat) == feat) return HCTR_OK;
-    Workspace ws;
-    ws.B = B; ws.W = W; ws.features = feat; ws.split = c->split;
     const int tilesW = (W + kTileW - 1) / kTileW;        // 16-column tiles (upper bound on tiles per row)
     const int Wa = (W + 31) / 32 * 32 + 2;               // room for the widest (32-column) tile + border
-    ws.Wa = Wa;
     const size_t cols = (size_t)B * W;
     const int m = c->chm();
-    // ---- layout: byte offsets into the arena, 256-byte aligned; core buffers first, optional parts behind them ----
+    // ---- layout: byte offsets into the arena, 256-byte aligned; core buffers first, optional parts behind them.
+    // Activation buffers, DEDICATED layout (default): every stage owns its input x[s] and three rotating block buffers,
+    // so a buffer keeps one geometry and its stored zero border survives from forward to forward (~245 kB per pixel
+    // column). ALIASED layout (HCTR_WS_ALIAS=1, or automatically when the dedicated one does not fit): four buffers of
+    // the largest stage geometry serve all stages - x[s] is pool 0 for every s (a stage input is dead after the stage's
+    // first block, long before conv_s+pool writes the next one), p[s][i] is pool 1 + i (dead once conv_s+pool has read
+    // the stage's last output) - ~95 kB per column; a buffer then changes geometry from stage to stage, so run_forward
+    // re-zeroes the borders at every stage entry (+15 small launches, ~0.5 % of a step).
+    Workspace ws;
     size_t off = 0;
     std::vector<std::pair<void**, size_t>> slots;
-    auto A = [&](auto** out, size_t count) {
-        slots.emplace_back((void**)out, off);
-        off += (std::max<size_t>(count * sizeof(**out), 16) + 255) & ~(size_t)255;
+    half_t* pool4[4] = {};
+    auto layout = [&](bool alias) {
+        ws = Workspace();
+        ws.B = B; ws.W = W; ws.features = feat; ws.split = c->split; ws.Wa = Wa; ws.aliased = alias;
+        off = 0;
+        slots.clear();
+        auto A = [&](auto** out, size_t count) {
+            slots.emplace_back((void**)out, off);
+            off += (std::max<size_t>(count * sizeof(**out), 16) + 255) & ~(size_t)255;
+        };
+        A((char**)&ws.img, cols * kImgH * 4);
+        A(&ws.widths, (size_t)B);
+        int cin = 64;
+        size_t se_max = 0, pool_elems = 0;
+        for (int s = 1; s <= 4; ++s) {
+            const int H = kStageH[s], planes = kStagePlanes[s - 1];
+            if (!alias) {
+                A(&ws.x[s], (size_t)act_elems(B, H, Wa, cin * m));
+                const int nbuf = (s == 4) ? 2 : 3;
+                for (int i = 0; i < nbuf; ++i) A(&ws.p[s][i], (size_t)act_elems(B, H, Wa, planes * m));
+            }
+            pool_elems = std::max(pool_elems, (size_t)act_elems(B, H, Wa, std::max(cin, planes) * m));
+            se_max = std::max(se_max, (size_t)B * (H / 8) * tilesW * planes);
+            cin = planes;
+        }
+        if (alias)
+            for (int i = 0; i < 4; ++i) A(&pool4[i], pool_elems);
+        A(&ws.headin, cols * kFeat * m);
+        A(&ws.se_part, se_max);
+        A(&ws.se_scale, (size_t)B * 512);
+        A(&ws.se_border, (size_t)B * 5 * 8 * 512);
+        A(&ws.se_mean, (size_t)B * 512);
+        A(&ws.se_counter, (size_t)B);
+        A(&ws.colidx, cols);
+        const size_t P = (size_t)head_parts_max(c);           // class parts per row of the fused head epilogues
+        A(&ws.amax_val, cols * P);
+        A(&ws.amax_idx, cols * P);
+        A(&ws.labels, cols);
+        A(&ws.lengths, (size_t)B);
+        A(&ws.tile_ctrs, (size_t)64 * 8);
+        // conv0_1's output (16 kB per column): only the unfused / f16x3 stem path
+        if (feat & WS_S0) A(&ws.s0, (size_t)act_elems(B, 128, Wa, 64 * m));
+        // [B*W][cpad] fp32 logits (3.8 GB at config 2): hctr_forward_logits and the HCTR_FUSE_* = 0 A/B paths only
+        if (feat & WS_LOGITS) A(&ws.logits, cols * c->cpad);
+        if (feat & WS_GUARD) {                               // guarded precision: runner-up / |logit| partials and figures
+            A(&ws.amax_val2, cols * P);
+            A(&ws.amax_abs, cols * P);
+            A(&ws.col_margin, cols);
+            A(&ws.col_abs, cols);
+            A(&ws.line_guard, (size_t)2 * B);
+        }
+        if (feat & WS_BEAM) {                                // scratch of the fused beam front end (kernels.h ConvArgs)
+            A(&ws.psum, P * cols);
+            A(&ws.blank_logit, cols);
+            A(&ws.row_thr, 2 * cols);
+            A(&ws.emit_cnt, cols);
+            A(&ws.esum, P * cols);
+            A(&ws.overflow, (size_t)1);
+            A(&ws.bm_idx, cols * kBeamMaxK);
+            A(&ws.bm_lp, cols * kBeamMaxK);
+            A(&ws.bm_bl, cols);
+            A(&ws.bm_st, 2 * cols);
+            A(&ws.bm_cnt, cols);
+            A(&ws.emit_list, cols * kBeamCap * 2);
+        }
     };
-    A((char**)&ws.img, cols * kImgH * 4);
-    A(&ws.widths, (size_t)B);
-    int cin = 64;
-    size_t se_max = 0;
-    for (int s = 1; s <= 4; ++s) {
-        const int H = kStageH[s], planes = kStagePlanes[s - 1];
-        A(&ws.x[s], (size_t)act_elems(B, H, Wa, cin * m));
-        const int nbuf = (s == 4) ? 2 : 3;
-        for (int i = 0; i < nbuf; ++i) A(&ws.p[s][i], (size_t)act_elems(B, H, Wa, planes * m));
-        se_max = std::max(se_max, (size_t)B * (H / 8) * tilesW * planes);
-        cin = planes;
-    }
-    A(&ws.headin, cols * kFeat * m);
-    A(&ws.se_part, se_max);
-    A(&ws.se_scale, (size_t)B * 512);
-    A(&ws.se_border, (size_t)B * 5 * 8 * 512);
-    A(&ws.se_mean, (size_t)B * 512);
-    A(&ws.se_counter, (size_t)B);
-    A(&ws.colidx, cols);
-    const size_t P = (size_t)head_parts_max(c);           // class parts per row of the fused head epilogues
-    A(&ws.amax_val, cols * P);
-    A(&ws.amax_idx, cols * P);
-    A(&ws.labels, cols);
-    A(&ws.lengths, (size_t)B);
-    A(&ws.tile_ctrs, (size_t)64 * 8);
-    // conv0_1's output (16 kB per column): only the unfused / f16x3 stem path
-    if (feat & WS_S0) A(&ws.s0, (size_t)act_elems(B, 128, Wa, 64 * m));
-    // [B*W][cpad] fp32 logits (3.8 GB at config 2): hctr_forward_logits and the HCTR_FUSE_* = 0 A/B paths only
-    if (feat & WS_LOGITS) A(&ws.logits, cols * c->cpad);
-    if (feat & WS_GUARD) {                               // guarded precision: runner-up / |logit| partials and figures
-        A(&ws.amax_val2, cols * P);
-        A(&ws.amax_abs, cols * P);
-        A(&ws.col_margin, cols);
-        A(&ws.col_abs, cols);
-        A(&ws.line_guard, (size_t)2 * B);
-    }
-    if (feat & WS_BEAM) {                                // scratch of the fused beam front end (kernels.h ConvArgs)
-        A(&ws.psum, P * cols);
-        A(&ws.blank_logit, cols);
-        A(&ws.row_thr, 2 * cols);
-        A(&ws.emit_cnt, cols);
-        A(&ws.esum, P * cols);
-        A(&ws.overflow, (size_t)1);
-        A(&ws.bm_idx, cols * kBeamMaxK);
-        A(&ws.bm_lp, cols * kBeamMaxK);
-        A(&ws.bm_bl, cols);
-        A(&ws.bm_st, 2 * cols);
-        A(&ws.bm_cnt, cols);
-        A(&ws.emit_list, cols * kBeamCap * 2);
+    bool alias = c->ws_alias == 1;
+    layout(alias);
+    if (c->ws_alias < 0 && off > c->arena_cap) {             // automatic: fall back to shared buffers when memory is short
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && off > free_b + c->arena_cap) {
+            alias = true;
+            layout(true);
+        }
     }
     bool fresh = false;
     if (off > c->arena_cap) {
@@ -524,12 +553,19 @@ int ensure_workspace(hctr_ctx* c, int B, int W, int features = 0) {
         fresh = true;
     }
     for (auto& sl : slots) *sl.first = c->arena + sl.second;
+    if (ws.aliased) {
+        for (int s = 1; s <= 4; ++s) {
+            ws.x[s] = pool4[0];
+            for (int i = 0; i < ((s == 4) ? 2 : 3); ++i) ws.p[s][i] = pool4[1 + i];
+        }
+    }
+    if (c->ws.aliased != ws.aliased) same_shape = false;
     // ---- stored conv borders: every activation buffer's border rows / columns must read as zero. The interiors are
     //      rewritten by each forward, so after a shape change (or a new arena) only the borders are cleared. ----
     auto zero_act = [&](half_t* p, int H, int C) { return launch_zero_borders(p, B, H, W, Wa, C * m, c->stream); };
     if (fresh || !same_shape) {
         int ci = 64;
-        for (int s = 1; s <= 4; ++s) {
+        for (int s = 1; s <= 4 && !ws.aliased; ++s) {        // (aliased layout: run_forward zeroes at every stage entry)
             const int H = kStageH[s], planes = kStagePlanes[s - 1];
             HIP_TRY(c, zero_act(ws.x[s], H, ci));
             const int nbuf = (s == 4) ? 2 : 3;
@@ -758,6 +794,20 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths, HeadMode mode = HEAD
         HIP_TRY(c, hipMemsetAsync(ws.tile_ctrs, 0, 64 * 8 * 4, c->stream));
         c->conv_seq = 0;
     }
+    // aliased workspace: a buffer changes geometry from stage to stage, so the stored zero borders of a stage's buffers
+    // are re-established when the stage is entered (the buffers' previous users are dead by then, see ensure_workspace)
+    auto zero_stage = [&](int s, bool input, bool blocks) -> int {
+        if (!ws.aliased) return HCTR_OK;
+        const int H = kStageH[s], planes = kStagePlanes[s - 1], cin_s = s == 1 ? 64 : kStagePlanes[s - 2];
+        const int mm = c->chm();
+        pf.begin("zero_borders");
+        if (input) HIP_TRY(c, launch_zero_borders(ws.x[s], ws.B, H, ws.W, ws.Wa, cin_s * mm, c->stream));
+        for (int i = 0; blocks && i < ((s == 4) ? 2 : 3); ++i)
+            HIP_TRY(c, launch_zero_borders(ws.p[s][i], ws.B, H, ws.W, ws.Wa, planes * mm, c->stream));
+        pf.end();
+        return HCTR_OK;
+    };
+    TRY(zero_stage(1, true, true));
     c->out_class = 8;
     if (c->fuse_stem && !c->split) {
         // conv0_1's output (16 kB per pixel column) never reaches HBM: it is computed into conv0_2's LDS halo
@@ -790,9 +840,11 @@ int run_forward(hctr_ctx* c, int img_f32, bool have_widths, HeadMode mode = HEAD
         char nm[32];
         snprintf(nm, sizeof(nm), "conv%d+pool", s);
         c->out_class = s < 4 ? 8 : 16;            // (conv4+pool writes the head input)
-        if (s < 4)
+        if (s < 4) {
+            TRY(zero_stage(s + 1, true, false));                 // x[s+1] = pool 0: dead since this stage's first block
             TRY(run_conv(c, pf, nm, wt.stage_conv[s - 1], cur, ws.x[s + 1], H / 2, true, true, nullptr, false));
-        else
+            TRY(zero_stage(s + 1, false, true));                 // the block buffers: dead once the launch above has read `cur`
+        } else
             TRY(run_conv(c, pf, nm, wt.stage_conv[s - 1], cur, ws.headin, H / 2, true, true, nullptr, true));
         cin = planes;
     }
@@ -996,6 +1048,7 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
         if (const char* fs2 = getenv("HCTR_FUSE_STEM")) c->fuse_stem = atoi(fs2) != 0;
         if (const char* ps = getenv("HCTR_PERSIST")) c->persist_dynamic = atoi(ps) == 2;
         if (const char* xm = getenv("HCTR_X3_MASK")) c->x3_mask = atoi(xm) & 31;
+        if (const char* wa = getenv("HCTR_WS_ALIAS")) c->ws_alias = atoi(wa) != 0 ? 1 : 0;
         if (const char* mc = getenv("HCTR_MAX_COLS")) {
             const long long v = atoll(mc);
             if (v > 0) c->max_cols = v;
@@ -1724,6 +1777,9 @@ int64_t hctr_debug_activation(hctr_ctx* c, const char* name, float* out, int64_t
             if (!p) return fail(c, HCTR_ERR_ARG, "buffer %s not allocated", name);
         }
         else return fail(c, HCTR_ERR_ARG, "unknown activation '%s'", name);
+        if (ws.aliased && !(n == "stage3" || n == "stage4" || (n.size() == 4 && n[0] == 'p' && n[1] == '4')))
+            return fail(c, HCTR_ERR_STATE, "activation '%s' was overwritten by a later stage: the stages share their buffers "
+                        "in this workspace layout (HCTR_WS_ALIAS=0 keeps every stage's own)", name);
         const int64_t total = (int64_t)ws.B * C * H * ws.W;
         if (Cout) *Cout = C;
         if (Hout) *Hout = H;

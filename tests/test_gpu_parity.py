@@ -572,7 +572,7 @@ def test_full_size_config2_properties(engine, codec, synth):
 @pytest.mark.parametrize("env", [{"HCTR_HALO": "0"}, {"HCTR_HALO": "1"}, {"HCTR_HALO": "0", "HCTR_PIPE": "1"},
                                  {"HCTR_FUSE_SE": "0"}, {"HCTR_HALO": "0", "HCTR_BIG_TILES": "0"},
                                  {"HCTR_PERSIST": "1"}, {"HCTR_PERSIST": "2"}, {"HCTR_FUSE_ARGMAX": "0"}, {"HCTR_FUSE_DS": "0"},
-                                 {"HCTR_FUSE_STEM": "0"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+                                 {"HCTR_FUSE_STEM": "0"}, {"HCTR_WS_ALIAS": "1"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_alternative_kernel_paths(env):
     """The A/B kernels (generic 64x256/128x128/256x256 tiles, 8-wave halo, interleaved pipe, unfused SE,
     persistent tiles) stay correct: same fixture and tolerances as the default path. Kernel selection is
@@ -1138,3 +1138,42 @@ def test_config5_full_size_beam_batch():
         assert pipe.recognize_beam(m, cd, imgs, chunk=chunk) == seq, chunk
     # greedy text of the same batch through the fused path, for the six golden lines
     assert cd.labels_to_text(m.greedy(imgs[:gold["lines"]])) == gold["greedy"]
+
+
+def test_aliased_workspace_layout_gives_identical_results(pkg, synth, state_dict):
+    """HCTR_WS_ALIAS=1: the four stages share four activation buffers (a buffer changes geometry from stage to stage and
+    run_forward re-zeroes the stored conv borders at every stage entry) instead of owning 15 dedicated ones. Same kernels,
+    same data: labels and logits must be bit-identical to the dedicated layout's, over shape changes, unequal widths and
+    all three precision modes; the arena of config 2 (64 x 2000) must stay below 13 GB (dedicated: 31 GB)."""
+    C = synth.DEFAULT_VOCAB + 2
+    ref = pkg.hctr_model(C, precision="auto").cuda(0)
+    ref.load_state_dict(state_dict)
+    os.environ["HCTR_WS_ALIAS"] = "1"                     # (read when the context is created)
+    try:
+        m = pkg.hctr_model(C, precision="auto").cuda(0)
+        m.load_state_dict(state_dict)
+    finally:
+        os.environ.pop("HCTR_WS_ALIAS", None)
+    cases = [(3, 200, None), (2, 333, [333, 120]), (5, 64, None), (1, 1000, None), (4, 97, [97, 64, 33, 5]), (3, 200, None)]
+    for mode in ("f16", "f16x3", "auto"):
+        ref.set_precision(mode)
+        m.set_precision(mode)
+        for i, (b, w, wd) in enumerate(cases):
+            imgs = synth.make_line_images(b, w, 90 + i)
+            wd = None if wd is None else np.array(wd, np.int32)
+            a, r = m.greedy(imgs, widths=wd), ref.greedy(imgs, widths=wd)
+            assert all(np.array_equal(x, y) for x, y in zip(a, r)), (mode, b, w)
+            if w <= 200:
+                assert np.array_equal(m(imgs, widths=wd), ref(imgs, widths=wd)), (mode, b, w)
+    fe, fr = m.beam_frontend(imgs, k=10, want_candidates=True), ref.beam_frontend(imgs, k=10, want_candidates=True)
+    assert all(np.array_equal(fe[k], fr[k]) for k in ("topk_idx", "topk_logp", "blank_logp", "cand_off"))
+    with pytest.raises(RuntimeError):
+        m.debug_activation("stage1", 3)                   # overwritten by later stages in this layout
+    # full size (f16): identical labels, a third of the memory
+    m.set_precision("f16")
+    ref.set_precision("f16")
+    big = synth.make_line_images(64, 2000, 2)
+    a, r = m.greedy(big), ref.greedy(big)
+    assert all(np.array_equal(x, y) for x, y in zip(a, r))
+    sa, sr = m.workspace_stats(), ref.workspace_stats()
+    assert sa["arena_bytes"] <= 13e9 < sr["arena_bytes"], (sa, sr)
