@@ -1169,9 +1169,16 @@ def test_aliased_workspace_layout_gives_identical_results(pkg, synth, state_dict
     assert all(np.array_equal(fe[k], fr[k]) for k in ("topk_idx", "topk_logp", "blank_logp", "cand_off"))
     with pytest.raises(RuntimeError):
         m.debug_activation("stage1", 3)                   # overwritten by later stages in this layout
-    # full size (f16): identical labels, a third of the memory
-    m.set_precision("f16")
-    ref.set_precision("f16")
+    # full size (f16, fresh contexts without the optional logits / beam parts): identical labels, a third of the memory
+    del m, ref
+    ref = pkg.hctr_model(C).cuda(0)
+    ref.load_state_dict(state_dict)
+    os.environ["HCTR_WS_ALIAS"] = "1"
+    try:
+        m = pkg.hctr_model(C).cuda(0)
+        m.load_state_dict(state_dict)
+    finally:
+        os.environ.pop("HCTR_WS_ALIAS", None)
     big = synth.make_line_images(64, 2000, 2)
     a, r = m.greedy(big), ref.greedy(big)
     assert all(np.array_equal(x, y) for x, y in zip(a, r))
