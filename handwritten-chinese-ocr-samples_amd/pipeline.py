@@ -32,11 +32,15 @@ def chunk_schedule(n, chunk, tail=16):
     return out
 
 
-def recognize_beam(model, codec, images, widths=None, chunk=64, taper=True):
+def recognize_beam(model, codec, images, widths=None, chunk=64, taper=True, stats=None):
     """Beam-decode ``images`` (uint8 [B,128,W] numpy array or torch tensor, optionally per-line widths)
     with ``codec``'s beam settings. Returns the decoded strings in input order. Every chunk is padded /
-    processed exactly like a batch of its own (same results as calling the two stages back to back)."""
+    processed exactly like a batch of its own (same results as calling the two stages back to back).
+    ``stats`` (optional dict) receives per-chunk wall times: "frontend_ms", "search_ms" and "consumer_wait_ms"."""
+    import time
     n = int(images.shape[0])
+    if stats is not None:
+        stats.update({"chunks": [], "frontend_ms": [], "search_ms": [], "consumer_wait_ms": []})
     spans = chunk_schedule(n, chunk) if taper else [(lo, min(n, lo + chunk)) for lo in range(0, n, chunk)]
     k = min(int(codec.search_depth), int(model.noutput))
     q = queue.Queue(maxsize=2)
@@ -49,7 +53,11 @@ def recognize_beam(model, codec, images, widths=None, chunk=64, taper=True):
                 if stop.is_set():
                     break
                 wd = None if widths is None else widths[lo:hi]
+                t0 = time.perf_counter()
                 fe = model.beam_frontend(images[lo:hi], k=k, widths=wd, want_candidates=codec.skip_search)
+                if stats is not None:
+                    stats["chunks"].append(hi - lo)
+                    stats["frontend_ms"].append(round((time.perf_counter() - t0) * 1e3, 2))
                 while not stop.is_set():
                     try:
                         q.put((lo, fe), timeout=0.1)
@@ -72,12 +80,17 @@ def recognize_beam(model, codec, images, widths=None, chunk=64, taper=True):
     out = [None] * n
     try:
         while True:
+            t0 = time.perf_counter()
             item = q.get()
+            t1 = time.perf_counter()
             if item is None:
                 break
             lo, fe = item
             for i, text in enumerate(codec.decode_frontend(fe)):
                 out[lo + i] = text
+            if stats is not None:
+                stats["consumer_wait_ms"].append(round((t1 - t0) * 1e3, 2))
+                stats["search_ms"].append(round((time.perf_counter() - t1) * 1e3, 2))
     finally:
         # an exception in the search (e.g. the reference-compatible IndexError of an empty line) must not leave
         # the producer running on the model's single-threaded engine context: stop it, unblock it, wait for it

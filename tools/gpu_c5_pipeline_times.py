@@ -51,3 +51,17 @@ print("concurrently: front end %.1f ms/chunk, host search %.1f ms/chunk, wall %.
 for nt in (16, 32, 64, 128):
     codec.num_threads = nt
     t0 = time.perf_counter(); codec.decode_frontend(fes[0]); print("host search, %d threads: %.1f ms" % (nt, (time.perf_counter() - t0) * 1e3))
+
+# the real pipeline (pipeline.recognize_beam), per-chunk wall times of both stages
+import importlib  # noqa: E402
+pipe = importlib.import_module(hctr_amd.package.__name__ + ".pipeline")
+codec.num_threads = 0
+for chunk, taper in ((64, True), (64, False), (32, True), (32, False)):
+    pipe.recognize_beam(model, codec, imgs, chunk=chunk, taper=taper)          # warm (workspace shapes)
+    st = {}
+    t0 = time.perf_counter()
+    pipe.recognize_beam(model, codec, imgs, chunk=chunk, taper=taper, stats=st)
+    dt = time.perf_counter() - t0
+    print("pipeline chunk=%d taper=%s: %.1f ms (%.1f lines/s)  chunks %s\n  front end ms %s (sum %.1f)\n  search ms %s\n  consumer wait ms %s"
+          % (chunk, taper, dt * 1e3, 256 / dt, st["chunks"], st["frontend_ms"], sum(st["frontend_ms"]), st["search_ms"], st["consumer_wait_ms"]))
+t0 = time.perf_counter(); fe = model.beam_frontend(imgs, k=10); print("one front-end call, 256 lines: %.1f ms" % ((time.perf_counter() - t0) * 1e3))
