@@ -138,6 +138,7 @@ struct hctr_ctx {
     size_t arena_cap = 0;
     int ws_sticky = 0;                  // optional parts this context has needed so far (kept in later layouts)
     int64_t arena_reallocs = 0, ws_recarves = 0;
+    bool rtouch = true;                 // HCTR_RTOUCH=0: no residual pre-touch in conv2's K loop (A/B)
     int ws_alias = -1;                  // HCTR_WS_ALIAS: 1 = stages share four activation buffers, 0 = never, -1 = only when
                                         // the dedicated layout does not fit into the device's free memory
     int64_t max_cols = kDefaultMaxCols;
@@ -638,6 +639,7 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
     ConvArgs a{};
     a.x = in.p; a.w = cw.w; a.bias = cw.bias; a.y = out; a.se_part = se_part;
     a.se_scale = se_scale; a.resid = resid;
+    a.rtouch = c->rtouch ? 1 : 0;
     a.split = c->split ? 1 : 0;
     a.drop_lo = (c->split && !(c->x3_mask & c->out_class)) ? 1 : 0;
     const int m = c->chm();                        // cw.cin already counts the tripled input channels
@@ -679,6 +681,9 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
         a.stamps = c->stamp_buf;
         c->stamp_n = (int64_t)a.mtiles * a.ntiles;
     }
+    static const char* dbg_layer = getenv("HCTR_DBG_LAYER");          // timing experiments on ONE layer (kernels.hip env_dbg)
+    if (dbg_layer && strcmp(dbg_layer, name) == 0)
+        if (const char* e = getenv("HCTR_DBG")) a.dbg = atoi(e);
     pf.begin(name);
     if (stem_img_f32 >= 0) {      // conv0_2 with conv0_1 computed in its loader from the staged image (kernels.hip)
         if (tile != TILE_64x256 || cw.taps != 9 || cw.cin != 64 || cw.coutPad != 64 || c->split)
@@ -1048,6 +1053,7 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
         if (const char* fs2 = getenv("HCTR_FUSE_STEM")) c->fuse_stem = atoi(fs2) != 0;
         if (const char* ps = getenv("HCTR_PERSIST")) c->persist_dynamic = atoi(ps) == 2;
         if (const char* xm = getenv("HCTR_X3_MASK")) c->x3_mask = atoi(xm) & 31;
+        if (const char* rt = getenv("HCTR_RTOUCH")) c->rtouch = atoi(rt) != 0;
         if (const char* wa = getenv("HCTR_WS_ALIAS")) c->ws_alias = atoi(wa) != 0 ? 1 : 0;
         if (const char* mc = getenv("HCTR_MAX_COLS")) {
             const long long v = atoll(mc);

@@ -68,6 +68,7 @@ struct ConvArgs {
     const float* stem_b;
     int split;              // f16x3 mode: activations are [hi | lo | hi] fp16 planes of Cout channels each
                             // (input side: Cin already counts the tripled channels)
+    int rtouch;             // halo4 kernel, conv2 of an identity block: pre-touch the residual tile's cache lines (HCTR_RTOUCH)
     int drop_lo;            // f16x3 diagnostic (HCTR_X3_MASK, precision attribution): round this layer's output to ONE fp16
                             // value like the f16 mode does (the lo plane is written as zeros)
     // fused 1x1 downsample of a block's input (first block of stages 1-3): the halo4 kernel first accumulates
