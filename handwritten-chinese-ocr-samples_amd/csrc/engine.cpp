@@ -138,7 +138,7 @@ struct hctr_ctx {
     size_t arena_cap = 0;
     int ws_sticky = 0;                  // optional parts this context has needed so far (kept in later layouts)
     int64_t arena_reallocs = 0, ws_recarves = 0;
-    bool rtouch = true;                 // HCTR_RTOUCH=0: no residual pre-touch in conv2's K loop (A/B)
+    bool rtouch = false;                // HCTR_RTOUCH=1: residual pre-touch in conv2's K loop (A/B; measured neutral)
     int ws_alias = -1;                  // HCTR_WS_ALIAS: 1 = stages share four activation buffers, 0 = never, -1 = only when
                                         // the dedicated layout does not fit into the device's free memory
     int64_t max_cols = kDefaultMaxCols;

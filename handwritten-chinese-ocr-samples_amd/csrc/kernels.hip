@@ -1187,12 +1187,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         // hipcc's counter model "dirty" on every iteration (scalar loads return out of order), and it then
         // drains lgkmcnt(0) at the first MFMA group of each K step instead of the counted wait.
         __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0), vmcnt/expcnt untouched
-        // Residual pre-touch (conv2 of an identity block): the epilogue's residual loads used to pay a full HBM round trip
-        // per tile (3.6 us of a 6.6 us epilogue, and the epilogue is NOT hidden by the partner workgroup: a launch costs
-        // loop time + per-tile overhead, profiles/r03_overhead_experiments.txt). Three steps before the end every thread
-        // touches the two 128-byte lines of one pixel of the residual tile with 4-byte LDS-DMA loads into the epilogue's
-        // scratch (no register destination): the lines are in L2 when the epilogue asks for them. The two loads are
-        // issued after that step's weight pieces, so the next step's counted wait leaves them in flight.
+        // Residual pre-touch (A/B experiment, HCTR_RTOUCH=1, OFF by default): three steps before the end every thread
+        // touches the two 128-byte lines of one pixel of conv2's residual tile with 4-byte LDS-DMA loads into the
+        // epilogue's scratch (no register destination; issued after that step's weight pieces, so the next step's counted
+        // wait leaves them in flight). Measured (profiles/r03_overhead_experiments.txt): the epilogue's residual phase
+        // drops 3.6 -> 2.7 us, the K loop grows by as much, the step time is unchanged - the phase is the latency of 16
+        // dependent-free loads through a busy memory pipeline, not an HBM miss.
         const bool rtouch = !SPLIT && !DSFUSE && a.rtouch && a.resid != nullptr && nk >= 6;
         const int ktouch = nk - 3;
         for (int kc = 0; kc < nkc; ++kc) {
