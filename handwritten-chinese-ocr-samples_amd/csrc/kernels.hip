@@ -20,6 +20,20 @@
 #ifndef NOPRIO
 #define NOPRIO 0       // A/B build switch (tools/ab_build.sh): 1 drops the s_setprio around MFMA groups
 #endif
+#ifndef GEN_PRIO
+#define GEN_PRIO 0     // A/B: generic conv_mfma kernel (head GEMM): 1 = static priority 1 over the whole K loop instead of flips
+#endif
+#ifndef STEM_PRIO
+#define STEM_PRIO 0    // A/B: fused stem kernel: 1 = static priority 1 over the whole conv0_2 (MFMA) phase instead of flips
+#endif
+#ifndef PRIO_MODE
+#define PRIO_MODE 1    // A/B build switch, halo4 kernel: 0 = priority 1 around every MFMA group, 0 elsewhere; 1 = the whole K
+                       // loop at priority 1 (its LDS reads / DMA issue / barrier beat the partner workgroup's epilogue and
+                       // prologue VALU work, which stays at 0), no per-group flips; 2 = loop at 1, MFMA groups at 2;
+                       // 3 = as 0 inside the loop, but prologue and epilogue at priority 2 (a slot's overhead phases are
+                       // short and fully exposed: let them win the issue port against the partner's loop);
+                       // 4 = as 1, with the prologue at priority 1 too (only the epilogue at 0)
+#endif
 
 namespace hctr {
 
@@ -625,6 +639,7 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
     const int foff1 = frow * 128 + (((4 + q) ^ (lane & 7)) << 4);
 
     stage(0, 0);
+    if (GEN_PRIO) __builtin_amdgcn_s_setprio(1);
     if (!PIPE) {
         for (int k = 0; k < nk; ++k) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -640,13 +655,13 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
                 for (int n = 0; n < 4; ++n) bf[n] = *(const f16x8*)(xt + n * 2048 + fo);
 #pragma unroll
                 for (int j = 0; j < JT; ++j) af[j] = *(const f16x8*)(wt + j * 2048 + fo);
-                __builtin_amdgcn_s_setprio(1);     // keeps the MFMA cluster together (measured +4 %)
+                if (!GEN_PRIO) __builtin_amdgcn_s_setprio(1);     // keeps the MFMA cluster together (measured +4 %)
 #pragma unroll
                 for (int j = 0; j < JT; ++j)
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
                         acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], bf[n], acc[j][n], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
+                if (!GEN_PRIO) __builtin_amdgcn_s_setprio(0);
             }
         }
     } else {
@@ -695,6 +710,7 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
         }
     }
 
+    if (GEN_PRIO) __builtin_amdgcn_s_setprio(0);
     conv_epilogue<WN, WM, JT, LINEAR, SPLIT>(a, acc, smem, tid, lane, wn, wm, n0, mt, img, th, tw,
                                              th * (4 * WM) + wm * 4, tw * kTileW);
 }
@@ -944,6 +960,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         if (STAMP && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + i] = __builtin_amdgcn_s_memrealtime();
     };
     stamp(0);
+    if (PRIO_MODE == 3) __builtin_amdgcn_s_setprio(2);
+    if (PRIO_MODE == 4) __builtin_amdgcn_s_setprio(1);
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv;
@@ -1094,14 +1112,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 if (g + RING - 1 < 8) read_a(g + RING - 1, ar[(g + RING - 1) % RING]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (g == BHALF_AT) { read_b(1, bq[1]); __builtin_amdgcn_sched_barrier(0); }
-                if (!(NOPRIO)) __builtin_amdgcn_s_setprio(1);
+                if (!(NOPRIO) && (PRIO_MODE == 0 || PRIO_MODE == 3)) __builtin_amdgcn_s_setprio(1);
+                if (PRIO_MODE == 2) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
                         acc[2 * jp + jj][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                             ar[g % RING][jj], bq[ks][n], acc[2 * jp + jj][n], 0, 0, 0);
-                if (!(NOPRIO)) __builtin_amdgcn_s_setprio(0);
+                if (!(NOPRIO) && (PRIO_MODE == 0 || PRIO_MODE == 3)) __builtin_amdgcn_s_setprio(0);
+                if (PRIO_MODE == 2) __builtin_amdgcn_s_setprio(1);
                 if (DMA_SPREAD == 1 && g < 4) stage_piece(g);
                 if (DMA_SPREAD == 2 && (g & 1) == 0) stage_piece(g >> 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1120,6 +1140,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             lane_offsets(cin, a.in_sh, woff, false);
             stage_halo(dxb, 0);
             stage_w(dwb, dcin, woff_x, 0, 0, 0);
+            if (PRIO_MODE == 1 || PRIO_MODE == 2 || PRIO_MODE == 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int j = 0; j < JT; ++j)
 #pragma unroll
@@ -1195,6 +1216,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         // dependent-free loads through a busy memory pipeline, not an HBM miss.
         const bool rtouch = !SPLIT && !DSFUSE && a.rtouch && a.resid != nullptr && nk >= 6;
         const int ktouch = nk - 3;
+        if (PRIO_MODE == 1 || PRIO_MODE == 2 || PRIO_MODE == 4) __builtin_amdgcn_s_setprio(1);
+        if (PRIO_MODE == 3) __builtin_amdgcn_s_setprio(0);
         for (int kc = 0; kc < nkc; ++kc) {
             const bool next_chunk = kc + 1 < nkc;
 #pragma unroll 1
@@ -1240,6 +1263,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 else stage_halo(nxb, 0);
             }
         }
+        if (PRIO_MODE == 1 || PRIO_MODE == 2 || PRIO_MODE == 4) __builtin_amdgcn_s_setprio(0);
+        if (PRIO_MODE == 3) __builtin_amdgcn_s_setprio(2);
         // the epilogue's scratch (SE partial sums) lives after the DMA buffers, so DMA may stay in flight
         stamp(3);
         if (a.dbg & 128) {       // dbg 128: timing experiment without the epilogue (keeps the MFMAs alive)
@@ -1640,6 +1665,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv0_2_kernel(const ConvArgs a) 
     for (int j = 0; j < JT; ++j)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (STEM_PRIO) __builtin_amdgcn_s_setprio(1);
     for (int st = 0; st < 5; ++st) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's weight pieces of step st have landed
         __syncthreads();                                               // ... everyone's, and (st == 0) the halo is written
@@ -1661,16 +1687,17 @@ __global__ __launch_bounds__(256, 2) void stem_conv0_2_kernel(const ConvArgs a) 
                 for (int n = 0; n < 4; ++n) bf[n] = *(const f16x8*)((((n & 1) ^ ks) ? bo : be) + n * (S * 128));
 #pragma unroll
                 for (int j = 0; j < JT; ++j) af[j] = *(const f16x8*)(wtile + j * 2048 + (ks ? aoff1 : aoff0));
-                __builtin_amdgcn_s_setprio(1);
+                if (!STEM_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < JT; ++j)
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
                         acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], bf[n], acc[j][n], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
+                if (!STEM_PRIO) __builtin_amdgcn_s_setprio(0);
             }
         }
     }
+    if (STEM_PRIO) __builtin_amdgcn_s_setprio(0);
     conv_epilogue<1, 4, JT, false, false>(a, acc, smem, tid, lane, 0, wv, 0, lin, img, th, tw, th * 16 + wrow, tw * 16);
 }
 
