@@ -35,6 +35,10 @@ struct ConvArgs {
     int64_t M;              // linear mode: number of rows
     int64_t ldo;            // linear mode: output leading dimension (elements)
     int mtiles, ntiles;
+    // halo4 kernel prologue without runtime divisions (set by launch_conv): ntiles and tilesH as shifts when they are
+    // powers of two (-1 otherwise: the kernel divides), mt / tilesW as (mt * tw_magic) >> 40 (exact for mt * tilesW < 2^40)
+    int nt_shift, th_shift;
+    uint64_t tw_magic;
     // linear mode, fused greedy argmax (np.argmax(preds, 2), utils/ctc_codec.py:75): when amax_idx is set the
     // logits are NOT stored; every wave column (nt, wn) writes its best (value, class) of each row to
     // amax_val/amax_idx[(nt*WN + wn) * M + m]; launch_argmax_partials picks the first maximum per row.

@@ -362,6 +362,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
                 __syncthreads();                   // main-loop LDS no longer needed
             }
             float* red = (float*)smem;             // [WM][BN]
+            // Sum over the wave's 64 pixels per cout: first the lane's four rows, then a REDUCE-SCATTER butterfly over
+            // the 16 pixel columns of a lane row (DPP quad_perm xor 1, xor 2, row_half_mirror, row_mirror). At every
+            // level a lane keeps half of its values and hands the other half to its partner, so the 4 levels cost
+            // 16 + 8 + 4 + 2 exchanges instead of 4 x 32, and every lane ends with JT/4 finished sums (one store each,
+            // no masked writes). The additions are exactly the full butterfly's (pair sums, quad sums, half-row sums, row
+            // sums; an fp add commutes), so the results are bit-identical to summing every value in every lane.
+            // Which half a lane keeps must agree between mirror partners: bits e0 = b0^b2, e1 = b1^b2, e2 = b2^b3, e3 = b3
+            // of the column c = b3 b2 b1 b0 (c^1 flips only e0, c^2 only e1, c^7 only e2, c^15 only e3).
+            constexpr int NV = JT * 4;
+            float vals[NV];
 #pragma unroll
             for (int j = 0; j < JT; ++j)
 #pragma unroll
@@ -370,13 +380,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
                         t[n] = (float)__builtin_bit_cast(f16x2, P[j][n][i >> 1])[i & 1];
-                    float sum = (t[0] + t[1]) + (t[2] + t[3]);
-                    sum += dpp_f32<0xB1>(sum);            // quad_perm [1,0,3,2]
-                    sum += dpp_f32<0x4E>(sum);            // quad_perm [2,3,0,1]
-                    sum += dpp_f32<0x141>(sum);           // row_half_mirror
-                    sum += dpp_f32<0x140>(sum);           // row_mirror
-                    if (c == 0) red[wm * BN + wn * WC + q * 8 + co(j) + i] = sum;
+                    vals[j * 4 + i] = (t[0] + t[1]) + (t[2] + t[3]);
                 }
+            const bool e0 = ((c ^ (c >> 2)) & 1) != 0, e1 = (((c >> 1) ^ (c >> 2)) & 1) != 0;
+            const bool e2 = (((c >> 2) ^ (c >> 3)) & 1) != 0, e3 = ((c >> 3) & 1) != 0;
+            float r1[NV / 2], r2[NV / 4], r3[NV / 8], r4[NV / 16];
+#pragma unroll
+            for (int u = 0; u < NV / 2; ++u)
+                r1[u] = (e0 ? vals[2 * u + 1] : vals[2 * u]) + dpp_f32<0xB1>(e0 ? vals[2 * u] : vals[2 * u + 1]);
+#pragma unroll
+            for (int u = 0; u < NV / 4; ++u)
+                r2[u] = (e1 ? r1[2 * u + 1] : r1[2 * u]) + dpp_f32<0x4E>(e1 ? r1[2 * u] : r1[2 * u + 1]);
+#pragma unroll
+            for (int u = 0; u < NV / 8; ++u)
+                r3[u] = (e2 ? r2[2 * u + 1] : r2[2 * u]) + dpp_f32<0x141>(e2 ? r2[2 * u] : r2[2 * u + 1]);
+#pragma unroll
+            for (int u = 0; u < NV / 16; ++u)
+                r4[u] = (e3 ? r3[2 * u + 1] : r3[2 * u]) + dpp_f32<0x140>(e3 ? r3[2 * u] : r3[2 * u + 1]);
+            const int vlow = (e3 ? 8 : 0) + (e2 ? 4 : 0) + (e1 ? 2 : 0) + (e0 ? 1 : 0);
+#pragma unroll
+            for (int u = 0; u < NV / 16; ++u) {
+                const int v = 16 * u + vlow, j = v >> 2, i = v & 3;      // this lane's finished sum: value j*4 + i
+                red[wm * BN + wn * WC + q * 8 + ((j >> 2) * 64 + ((j >> 1) & 1) * 32 + (j & 1) * 4) + i] = r4[u];
+            }
             __syncthreads();
             if (tid < BN) {
                 float sum = 0.f;
@@ -973,6 +999,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     //      minor) order. Non-persistent: one tile per workgroup. Persistent: the workgroups of an XCD
     //      stride through its run, and a workgroup prefetches its NEXT tile's first halo and weights
     //      while the current tile's epilogue runs (the cold per-tile prologue is ~10-30 % of a launch).
+    // every kernel argument the prologue needs is requested here, in ONE batch of scalar loads and one wait (the compiler
+    // otherwise fetches them in three dependent rounds, each a scalar-cache round trip on the critical path to the first DMA)
+    {
+        const int k0 = a.mtiles, k1 = a.ntiles, k2 = a.tilesW, k3 = a.tilesH, k4 = a.Cin, k5 = a.in_sh, k6 = a.nt_shift,
+                  k7 = a.th_shift, k8 = a.CoutPad;
+        const uint64_t k9 = a.tw_magic;
+        const int64_t k10 = a.in_sb;
+        const half_t *k11 = a.x, *k12 = a.w;
+        const float* k13 = a.bias;
+        asm volatile("" ::"s"(k0), "s"(k1), "s"(k2), "s"(k3), "s"(k4), "s"(k5), "s"(k6), "s"(k7), "s"(k8), "s"(k9), "s"(k10),
+                     "s"(k11), "s"(k12), "s"(k13));
+    }
     const int total = a.mtiles * a.ntiles;
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const int tq = total >> 3, tr = total & 7;
@@ -983,20 +1021,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     auto tile_at = [&](int idx) {
         Tile t;
         const int lin = xbase_lin + idx;
-        const int nt = lin % a.ntiles;
-        t.mt = lin / a.ntiles;
+        int nt, t2, th, img;
+        if (a.nt_shift >= 0) { nt = lin & (a.ntiles - 1); t.mt = lin >> a.nt_shift; }
+        else { nt = lin % a.ntiles; t.mt = lin / a.ntiles; }
         t.n0 = nt * BN;
-        const int tw = t.mt % a.tilesW;
-        const int t2 = t.mt / a.tilesW;
-        const int th = t2 % a.tilesH;
-        const int img = t2 / a.tilesH;
+        t2 = (int)(((uint64_t)(uint32_t)t.mt * a.tw_magic) >> 40);          // = mt / tilesW (launch_conv checks the range)
+        const int tw = t.mt - t2 * a.tilesW;
+        if (a.th_shift >= 0) { th = t2 & (a.tilesH - 1); img = t2 >> a.th_shift; }
+        else { th = t2 % a.tilesH; img = t2 / a.tilesH; }
         t.img = img; t.th = th; t.tw = tw;
         t.xb = (const char*)(a.x + img * a.in_sb + (int64_t)(th * TR) * a.in_sh + (int64_t)(tw * TC) * cin);
         t.wb = (const char*)(a.w + (int64_t)t.n0 * cin);
         return t;
     };
     int tidx = local;
-    if (tidx >= xcnt) return;                       // (persistent grids may exceed a short XCD run)
+    if (PERSIST && tidx >= xcnt) return;            // (persistent grids may exceed a short XCD run; a plain grid is exact)
     // Persistent variant, DYNAMIC tile queue (a.tile_counter set): the first two tiles of a workgroup are the static
     // ones (local, local + nloc); every later tile index is drawn from the XCD's atomic counter one tile ahead, so the
     // draw's latency hides behind a whole K loop and the hardware dispatcher's balancing is kept.
@@ -1368,7 +1407,13 @@ static hipError_t launch_conv_halo4_t(const ConvArgs& a, hipStream_t s) {
     return launch_conv_halo4_tp<GEOM, SPLIT, true>(b, s);
 }
 template <int GEOM>
-static hipError_t launch_conv_halo4(const ConvArgs& a, hipStream_t s) {
+static hipError_t launch_conv_halo4(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;                 // division-free tile decomposition for the kernel's prologue
+    auto shift_of = [](int v) { int sft = 0; while ((1 << sft) < v) ++sft; return (1 << sft) == v ? sft : -1; };
+    a.nt_shift = shift_of(a.ntiles);
+    a.th_shift = shift_of(a.tilesH);
+    if (a.tilesW < 1 || (uint64_t)a.mtiles * (uint64_t)a.tilesW >= ((uint64_t)1 << 40)) return hipErrorInvalidValue;
+    a.tw_magic = (((uint64_t)1 << 40) + (uint64_t)a.tilesW - 1) / (uint64_t)a.tilesW;
     return a.split ? launch_conv_halo4_t<GEOM, true>(a, s) : launch_conv_halo4_t<GEOM, false>(a, s);
 }
 

@@ -1,6 +1,7 @@
 """Cross-check of two independent kernel families over many shapes (run on the GPU box):
     python tools/gpu_shape_sweep.py dump <file.npz>     (under whatever HCTR_* variables are set)
     python tools/gpu_shape_sweep.py compare a.npz b.npz
+    python tools/gpu_shape_sweep.py identical a.npz b.npz      (two builds that must agree bit for bit)
 `dump` stores, for ~30 random (lines, width, per-line widths) cases, the logits' per-column max / argmax and a
 class subsample; `compare` requires the two runs (e.g. default halo kernels vs HCTR_HALO=0 generic kernels with
 HCTR_FUSE_SE=0 HCTR_FUSE_DS=0 HCTR_FUSE_ARGMAX=0) to agree within fp16-pipeline noise on every case."""
@@ -66,8 +67,19 @@ def compare(pa, pb):
           (len(cases()), worst, agree_min))
 
 
+def identical(pa, pb):
+    """bit-for-bit equality of two dumps (two builds of the SAME arithmetic, e.g. a re-scheduled epilogue)"""
+    a, b = np.load(pa), np.load(pb)
+    assert sorted(a.files) == sorted(b.files)
+    bad = [k for k in a.files if not np.array_equal(a[k], b[k])]
+    assert not bad, bad[:8]
+    print("identical: %d arrays of %d cases" % (len(a.files), len(cases())))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "dump":
         dump(sys.argv[2])
+    elif sys.argv[1] == "identical":
+        identical(sys.argv[2], sys.argv[3])
     else:
         compare(sys.argv[2], sys.argv[3])
