@@ -138,6 +138,7 @@ struct hctr_ctx {
     size_t arena_cap = 0;
     int ws_sticky = 0;                  // optional parts this context has needed so far (kept in later layouts)
     int64_t arena_reallocs = 0, ws_recarves = 0;
+    bool rpre = true;                   // HCTR_RPRE=0/1 with a -DRPRE=1 build: conv2's residual fetched during the last K step (A/B, neutral)
     bool rtouch = false;                // HCTR_RTOUCH=1: residual pre-touch in conv2's K loop (A/B; measured neutral)
     int ws_alias = -1;                  // HCTR_WS_ALIAS: 1 = stages share four activation buffers, 0 = never, -1 = only when
                                         // the dedicated layout does not fit into the device's free memory
@@ -640,6 +641,7 @@ int run_conv(hctr_ctx* c, Prof& pf, const char* name, const ConvW& cw, ActDesc i
     a.x = in.p; a.w = cw.w; a.bias = cw.bias; a.y = out; a.se_part = se_part;
     a.se_scale = se_scale; a.resid = resid;
     a.rtouch = c->rtouch ? 1 : 0;
+    a.rpre = c->rpre ? 1 : 0;
     a.split = c->split ? 1 : 0;
     a.drop_lo = (c->split && !(c->x3_mask & c->out_class)) ? 1 : 0;
     const int m = c->chm();                        // cw.cin already counts the tripled input channels
@@ -1054,6 +1056,7 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
         if (const char* ps = getenv("HCTR_PERSIST")) c->persist_dynamic = atoi(ps) == 2;
         if (const char* xm = getenv("HCTR_X3_MASK")) c->x3_mask = atoi(xm) & 31;
         if (const char* rt = getenv("HCTR_RTOUCH")) c->rtouch = atoi(rt) != 0;
+        if (const char* rp = getenv("HCTR_RPRE")) c->rpre = atoi(rp) != 0;
         if (const char* wa = getenv("HCTR_WS_ALIAS")) c->ws_alias = atoi(wa) != 0 ? 1 : 0;
         if (const char* mc = getenv("HCTR_MAX_COLS")) {
             const long long v = atoll(mc);

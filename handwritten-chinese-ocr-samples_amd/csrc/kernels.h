@@ -72,6 +72,7 @@ struct ConvArgs {
     const float* stem_b;
     int split;              // f16x3 mode: activations are [hi | lo | hi] fp16 planes of Cout channels each
                             // (input side: Cin already counts the tripled channels)
+    int rpre;               // halo4 kernel, conv2 of an identity block: fetch the residual during the last K step (HCTR_RPRE)
     int rtouch;             // halo4 kernel, conv2 of an identity block: pre-touch the residual tile's cache lines (HCTR_RTOUCH)
     int drop_lo;            // f16x3 diagnostic (HCTR_X3_MASK, precision attribution): round this layer's output to ONE fp16
                             // value like the f16 mode does (the lo plane is written as zeros)

@@ -20,6 +20,16 @@
 #ifndef NOPRIO
 #define NOPRIO 0       // A/B build switch (tools/ab_build.sh): 1 drops the s_setprio around MFMA groups
 #endif
+#ifndef RPRE
+#define RPRE 0         // A/B build switch: 1 compiles the residual prefetch of conv2's last K step in (then HCTR_RPRE=0/1 selects it
+                       // at run time). Measured neutral (132.5-133.6 ms either way; the epilogue's residual phase stays 3.3 us
+                       // because the second half's loads still start there), so it is compiled out by default.
+#endif
+#ifndef RPRE_GROUPS
+#define RPRE_GROUPS 4  // MFMA groups of the last K step after which two residual vectors each are fetched: 4 = the 8 vectors of
+                       // the first 64-cout block (the most that stays in registers: 5, 6 and 8 groups spill 144 B per lane);
+                       // the second block's 8 vectors are loaded at the start of the epilogue
+#endif
 #ifndef GEN_PRIO
 #define GEN_PRIO 0     // A/B: generic conv_mfma kernel (head GEMM): 1 = static priority 1 over the whole K loop instead of flips
 #endif
@@ -107,7 +117,9 @@ template <int WN, int WM, int JT, bool LINEAR, bool SPLIT, bool PRIVATE_RED = fa
           bool RESID_IN_ACC = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT][4], char* smem, int tid, int lane,
                                               int wn, int wm, int n0, int mt, int img, int th, int tw, int hbase,
-                                              int w0, unsigned long long* st = nullptr) {
+                                              int w0, unsigned long long* st = nullptr,
+                                              const f16x8 (*pre_lo)[4] = nullptr, const f16x8 (*pre_hi)[4] = nullptr,
+                                              bool use_pre = false) {
     // diagnostic instance only: st = this workgroup's stamp slots 8.. (after bias, residual, rounding, SE sums)
     auto estamp = [&](int i) {
         if (st != nullptr) {
@@ -302,15 +314,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[JT
     } else if (a.se_scale != nullptr) {
         const float* sc = a.se_scale + (int64_t)img * a.Cout + cw0;
         if (w < a.out_wlimit) {
-            // all residual loads first (one latency exposure), 2 x 8 couts = 2 x 16 B per (cb, n)
+            // all residual loads first (one latency exposure), 2 x 8 couts = 2 x 16 B per (cb, n) - unless the caller has
+            // fetched them already (halo4 kernel: during its last K step, pre_lo / pre_hi)
             f16x8 rlo[JT / 4][4], rhi[JT / 4][4];
 #pragma unroll
             for (int cb = 0; cb < JT / 4; ++cb)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    const half_t* r = a.resid + pix0 + (int64_t)(hbase + n) * a.out_sh + cb * 64;
-                    rlo[cb][n] = *(const f16x8*)r;
-                    rhi[cb][n] = *(const f16x8*)(r + 32);
+                    if (pre_lo != nullptr && use_pre && cb * 4 + n < RPRE_GROUPS) {       // (pre_lo: compile-time per call site; use_pre: run time -
+                        rlo[cb][n] = pre_lo[cb][n];           //  a run-time SELECTED pointer would force the arrays into scratch)
+                        rhi[cb][n] = pre_hi[cb][n];
+                    } else {
+                        const half_t* r = a.resid + pix0 + (int64_t)(hbase + n) * a.out_sh + cb * 64;
+                        rlo[cb][n] = *(const f16x8*)r;
+                        rhi[cb][n] = *(const f16x8*)(r + 32);
+                    }
                 }
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
@@ -1122,7 +1140,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         // Rolling fragment pipeline: 8 groups of 8 MFMAs (2 A fragments x 4 B fragments); A pairs are read two
         // groups ahead into a 3-slot ring, the second half's B fragments during group 1; `stage_next` issues the
         // next step's weight DMA after the first reads so its issue cost overlaps their LDS latency.
-        auto mma_step = [&](const char* wt, const char* be, const char* bo, auto&& stage_next, auto&& stage_piece) {
+        auto mma_step = [&](const char* wt, const char* be, const char* bo, auto&& stage_next, auto&& stage_piece,
+                            auto&& after_group) {
             f16x8 ar[RING][2], bq[2][4];
             auto read_a = [&](int g, f16x8 (&dst)[2]) {
                 const int ks = g >> 2, jp = g & 3;
@@ -1163,6 +1182,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 if (PRIO_MODE == 2) __builtin_amdgcn_s_setprio(1);
                 if (DMA_SPREAD == 1 && g < 4) stage_piece(g);
                 if (DMA_SPREAD == 2 && (g & 1) == 0) stage_piece(g >> 1);
+                after_group(g);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -1195,7 +1215,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 mma_step(smem + (kc & 1) * 16384, be, bo, [&] {
                     if (kc + 1 < nds) stage_w(dwb, dcin, woff_x, kc + 1, 0, (kc + 1) & 1);
                     else stage_w(cur.wb, cin, woff, 0, 0, (kc + 1) & 1);            // conv2's first step
-                }, [&](int) {});
+                }, [&](int) {}, [&](int) {});
                 __builtin_amdgcn_s_barrier();                 // every wave has consumed this chunk's fragments
                 asm volatile("" ::: "memory");
                 if (kc + 1 < nds) {
@@ -1255,12 +1275,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         // dependent-free loads through a busy memory pipeline, not an HBM miss.
         const bool rtouch = !SPLIT && !DSFUSE && a.rtouch && a.resid != nullptr && nk >= 6;
         const int ktouch = nk - 3;
+        // residual prefetch during the last K step (f16, identity blocks; a.rpre: A/B switch HCTR_RPRE)
+        const bool rpre = RPRE && !SPLIT && !DSFUSE && !PERSIST && a.rpre && a.resid != nullptr && a.se_scale != nullptr && nk >= 1;
+
         if (PRIO_MODE == 1 || PRIO_MODE == 2 || PRIO_MODE == 4) __builtin_amdgcn_s_setprio(1);
         if (PRIO_MODE == 3) __builtin_amdgcn_s_setprio(0);
         for (int kc = 0; kc < nkc; ++kc) {
             const bool next_chunk = kc + 1 < nkc;
+            // with the residual prefetch the very last K step (tap 8 of the last chunk) runs after this loop, where the
+            // loop's per-lane DMA offsets are dead and their registers can hold the residual
+            const int ntap = (rpre && !next_chunk) ? 8 : 9;
 #pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {
+            for (int tap = 0; tap < ntap; ++tap) {
                 const int k = kc * 9 + tap;
                 if (rtouch && k == ktouch + 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1290,7 +1316,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                     }
                 }, [&](int i) {
                     if (more || has_next) stage_weights_piece(wsrc, kc1, tap1, (kbase + k + 1) & 1, i);
-                });
+                }, [&](int) {});
             }
             if ((next_chunk || has_next) && !(a.dbg & 32)) {     // dbg 32: timing experiment without the reload
                 // single halo buffer: every wave has consumed its last B fragments of this chunk (they fed
@@ -1301,6 +1327,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 if (next_chunk) stage_halo(cur.xb, kc + 1);
                 else stage_halo(nxb, 0);
             }
+        }
+        f16x8 rlo[2][4], rhi[2][4];
+        if (rpre) {
+            // LAST K step of a conv2 with an identity residual (non-persistent: nothing is staged any more): the 16
+            // residual vectors of the epilogue are fetched here, two after each MFMA group, into the registers the
+            // step's operand fragments and the loop's DMA offsets leave behind - their latency (2.7-3.6 us of a 6.6 us
+            // epilogue when issued there) hides under the step's MFMAs
+            const half_t* rbase = a.resid + a.out_off + cur.img * a.out_sb + (int64_t)(cur.tw * TC + wcol + c) * a.out_sw +
+                                  cur.n0 + q * 8 + (int64_t)(cur.th * TR + wrow) * a.out_sh;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const char *be, *bo;
+            b_ptrs(8, be, bo);
+            mma_step(smem + ((kbase + nk - 1) & 1) * 16384, be, bo, [&] {}, [&](int) {}, [&](int g) {
+                if (g < RPRE_GROUPS) {
+                    const half_t* r = rbase + (int64_t)(g & 3) * a.out_sh + (g >> 2) * 64;
+                    rlo[g >> 2][g & 3] = *(const f16x8*)r;
+                    rhi[g >> 2][g & 3] = *(const f16x8*)(r + 32);
+                }
+            });
         }
         if (PRIO_MODE == 1 || PRIO_MODE == 2 || PRIO_MODE == 4) __builtin_amdgcn_s_setprio(0);
         if (PRIO_MODE == 3) __builtin_amdgcn_s_setprio(2);
@@ -1318,7 +1365,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             const int tw = cur.tw, th = cur.th, img = cur.img;
             conv_epilogue<WN, WM, JT, false, SPLIT, true, true, DSFUSE>(a, acc, smem + kHalo4Lds, tid, lane, 0, wm, cur.n0, cur.mt,
                                                           img, th, tw, th * TR + wrow, tw * TC + wcol,
-                                                          STAMP ? a.stamps + (size_t)blockIdx.x * 16 : nullptr);
+                                                          STAMP ? a.stamps + (size_t)blockIdx.x * 16 : nullptr, rlo, rhi, rpre);
         }
         if (!has_next) break;
         kbase += nk;
