@@ -140,8 +140,9 @@ struct hctr_ctx {
     int64_t arena_reallocs = 0, ws_recarves = 0;
     bool rpre = true;                   // HCTR_RPRE=0/1 with a -DRPRE=1 build: conv2's residual fetched during the last K step (A/B, neutral)
     bool rtouch = false;                // HCTR_RTOUCH=1: residual pre-touch in conv2's K loop (A/B; measured neutral)
-    int ws_alias = -1;                  // HCTR_WS_ALIAS: 1 = stages share four activation buffers, 0 = never, -1 = only when
-                                        // the dedicated layout does not fit into the device's free memory
+    int ws_alias = -1;                  // HCTR_WS_ALIAS: 1 = stages share four activation buffers, 0 = never, -1 (default) = when
+                                        // the dedicated layout would exceed ws_dedicated_max bytes or the device's free memory
+    size_t ws_dedicated_max = (size_t)16 << 30;      // HCTR_WS_DEDICATED_MAX_GB
     int64_t max_cols = kDefaultMaxCols;
     bool big_tiles = true;
     int halo_mode = 2;
@@ -529,9 +530,16 @@ int ensure_workspace(hctr_ctx* c, int B, int W, int features = 0) {
     };
     bool alias = c->ws_alias == 1;
     layout(alias);
-    if (c->ws_alias < 0 && off > c->arena_cap) {             // automatic: fall back to shared buffers when memory is short
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && off > free_b + c->arena_cap) {
+    if (c->ws_alias < 0) {
+        // automatic: small shapes keep every stage's own buffers (no per-stage border zeroing, every debug tap readable);
+        // a layout beyond ws_dedicated_max (16 GiB: about 30 lines of 2000 columns), or one that would not fit into the
+        // device's free memory, uses the shared buffers (a third of the bytes, +0.3 % time)
+        bool want = off > c->ws_dedicated_max;
+        if (!want && off > c->arena_cap) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && off > free_b + c->arena_cap) want = true;
+        }
+        if (want) {
             alias = true;
             layout(true);
         }
@@ -1058,6 +1066,10 @@ int hctr_create(hctr_ctx** out, int device, int num_classes) {
         if (const char* rt = getenv("HCTR_RTOUCH")) c->rtouch = atoi(rt) != 0;
         if (const char* rp = getenv("HCTR_RPRE")) c->rpre = atoi(rp) != 0;
         if (const char* wa = getenv("HCTR_WS_ALIAS")) c->ws_alias = atoi(wa) != 0 ? 1 : 0;
+        if (const char* wd = getenv("HCTR_WS_DEDICATED_MAX_GB")) {
+            const double g = atof(wd);
+            if (g >= 0) c->ws_dedicated_max = (size_t)(g * 1073741824.0);
+        }
         if (const char* mc = getenv("HCTR_MAX_COLS")) {
             const long long v = atoll(mc);
             if (v > 0) c->max_cols = v;
