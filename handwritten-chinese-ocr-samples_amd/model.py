@@ -127,6 +127,9 @@ class hctr_model(object):
         _lib.check(lib.hctr_finalize_weights(self._ctx), self._ctx)
         self._loaded = True
         self._sd_host = sd
+        active = getattr(self, "_active_precision", None)
+        if active is not None and active != self.precision:       # a mode switched at run time survives a device move
+            _lib.check(lib.hctr_set_precision(self._ctx, _PRECISIONS[active]), self._ctx)
 
     def state_dict(self):
         """The checkpoint dict this model was loaded from (reference key schema, ``main.py:349-356``), as torch CPU

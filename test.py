@@ -65,6 +65,8 @@ def build_argparser():
     a.add_argument("-bl", "--beta-lower", type=float, default=4.2)
     a.add_argument("-bu", "--beta-upper", type=float, default=6.6)
     a.add_argument("-bc", "--beta-count", type=int, default=25)
+    # engine option (not a reference flag): f16 (default), f16x3, or auto = f16 with uncertain lines re-run in f16x3
+    a.add_argument("--precision", type=str, default=os.environ.get("HCTR_PRECISION", "f16"), choices=["f16", "f16x3", "auto"])
     return p
 
 
@@ -136,7 +138,7 @@ def build(args):
     characters = find_characters(args.input, synthetic)
     num_classes = 1 + len(characters) + 1                      # test.py:334
     print("Character vocabulary: {}, Model output classes: {}".format(len(characters), num_classes))
-    model = hctr_amd.hctr_model(num_classes=num_classes)
+    model = hctr_amd.hctr_model(num_classes=num_classes, precision=args.precision)
     codec = hctr_amd.ctc_codec(characters)
     print("Use GPU: {} for testing".format(args.gpu))
     model = model.cuda(args.gpu)
