@@ -262,3 +262,36 @@ def test_auto_mode_nan_and_ties_are_flagged(pkg, synth, state_dict):
     assert [lab.tolist() for lab in m2.greedy(imgs)] == [[], []]
     gd = m2.last_guard()
     assert gd["flagged"] == 2 and (gd["min_margin"] == 0).all() and (gd["scale"] == 0.25).all()
+
+
+def test_cli_precision_auto(tmp_path, pkg, synth, auto_random):
+    """test.py --precision auto (the drop-in CLI with ragged files in batches of 2, i.e. padded batches): the printed
+    strings are the f16x3 mode's for the same padded batches."""
+    import ast
+    import subprocess
+    import sys
+    from PIL import Image
+    from conftest import ROOT
+    folder = tmp_path / "lines"
+    folder.mkdir()
+    widths = [120, 64, 97, 97]
+    imgs = [synth.make_line_images(1, w, 700 + i)[0] for i, w in enumerate(widths)]
+    for i, im in enumerate(imgs):
+        Image.fromarray(im).save(folder / ("%06d.png" % i))
+    cd = pkg.ctc_codec(synth.characters())
+    auto_random.set_precision("f16x3")
+    want = []
+    for i in range(0, 4, 2):
+        w = max(widths[i:i + 2])
+        batch = np.zeros((2, 128, w), np.uint8)
+        for j in range(2):
+            batch[j, :, :widths[i + j]] = imgs[i + j]
+        want += cd.labels_to_text(auto_random.greedy(batch, widths=np.array(widths[i:i + 2], np.int32)))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "test.py"), "-m", "hctr", "-f", "synthetic", "-b", "2", "-i",
+                        str(folder), "-dm", "greedy-search", "--precision", "auto"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = []
+    for line in r.stdout.splitlines():
+        if line.startswith("predicted results: "):
+            got += ast.literal_eval(line[len("predicted results: "):])
+    assert got == want
