@@ -151,8 +151,8 @@ def test_auto_mode_config2_trained_checkpoint_equals_the_real_reference(pkg, syn
     assert gd["lines"] == 64 and 0 <= gd["flagged"] <= 12, gd["flagged"]       # reference margins: 5-6 lines below the bound
     tol = LOGIT_RTOL * float(np.abs(g["max"]).max()) + LOGIT_ATOL
     assert np.abs(gd["min_margin"] - g["margin"].min(axis=1)).max() <= 2 * tol
-    # every line whose REFERENCE margins are all above 4 * tol is certainly unflagged, every line with one below
-    # 2 * tol - 2 * tol = 0 ... (the engine's margin is within 2 * tol of the reference's)
+    # the engine's margin is within 2 * tol of the reference's, so a line whose REFERENCE margins all exceed 4 * tol
+    # cannot be flagged (the flag threshold is at most 2 * tol)
     ref_min = g["margin"].min(axis=1)
     assert not gd["flags"][ref_min > 4 * tol].any()
 
