@@ -30,6 +30,15 @@
                        // the first 64-cout block (the most that stays in registers: 5, 6 and 8 groups spill 144 B per lane);
                        // the second block's 8 vectors are loaded at the start of the epilogue
 #endif
+#ifndef GEN_ROLL
+#define GEN_ROLL 1     // A/B: generic kernel, 8-accumulator-tile waves (256x256 tile: the head GEMM): 1 = the halo kernels' rolling
+                       // fragment pipeline (A pairs read two MFMA groups ahead, second-half B fragments during group 1, the next
+                       // step's DMA burst after the first reads) instead of "all reads of a half step, then its 32 MFMAs"
+#endif
+#ifndef GEN_ASM_DMA
+#define GEN_ASM_DMA 1  // A/B: generic conv_mfma kernel (head GEMM, conv0_2 A/B paths): 1 = its LDS-DMA issued from inline asm like the
+                       // halo kernels (hidden from hipcc's waitcnt pass, which otherwise drains lgkmcnt(0) at every wait)
+#endif
 #ifndef GEN_PRIO
 #define GEN_PRIO 0     // A/B: generic conv_mfma kernel (head GEMM): 1 = static priority 1 over the whole K loop instead of flips
 #endif
@@ -657,10 +666,12 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
     auto stage_piece = [&](const char* wsrc, const char* xsrc, int buf, int idx) {
         if (idx < NIW) {
             char* wdst = smem + buf * TILE_BYTES + (wv * NIW) * 1024;
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + woff[idx]), (lptr_t)(wdst + idx * 1024), 16, 0, 0);
+            if (GEN_ASM_DMA) glds16_asm_s(wsrc, woff[idx], wdst + idx * 1024);
+            else __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + woff[idx]), (lptr_t)(wdst + idx * 1024), 16, 0, 0);
         } else {
             char* xdst = smem + buf * TILE_BYTES + BN * 128 + (wv * NIX) * 1024;
-            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc + xoff[idx - NIW]), (lptr_t)(xdst + (idx - NIW) * 1024), 16, 0, 0);
+            if (GEN_ASM_DMA) glds16_asm_s(xsrc, xoff[idx - NIW], xdst + (idx - NIW) * 1024);
+            else __builtin_amdgcn_global_load_lds((gptr_t)(xsrc + xoff[idx - NIW]), (lptr_t)(xdst + (idx - NIW) * 1024), 16, 0, 0);
         }
     };
     auto stage = [&](int k, int buf) {
@@ -688,9 +699,45 @@ __global__ __launch_bounds__(WN* WM * 64) void conv_mfma_kernel(const ConvArgs a
         for (int k = 0; k < nk; ++k) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (k + 1 < nk) stage(k + 1, (k + 1) & 1);
             const char* wt = smem + (k & 1) * TILE_BYTES + (wn * WC) * 128;
             const char* xt = smem + (k & 1) * TILE_BYTES + BN * 128 + (wm * 64) * 128;
+            if (GEN_ROLL && JT == 8) {
+                f16x8 ar[3][2], bq[2][4];
+                auto read_a = [&](int g, f16x8 (&dst)[2]) {
+                    const char* base = wt + ((g >> 2) ? foff1 : foff0);
+                    dst[0] = *(const f16x8*)(base + (2 * (g & 3)) * 2048);
+                    dst[1] = *(const f16x8*)(base + (2 * (g & 3) + 1) * 2048);
+                };
+                auto read_b = [&](int ks, f16x8 (&dst)[4]) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) dst[n] = *(const f16x8*)(xt + n * 2048 + (ks ? foff1 : foff0));
+                };
+                __builtin_amdgcn_sched_barrier(0);
+                read_b(0, bq[0]);
+                read_a(0, ar[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                read_a(1, ar[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < nk) stage(k + 1, (k + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    if (g + 2 < 8) read_a(g + 2, ar[(g + 2) % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g == 1) { read_b(1, bq[1]); __builtin_amdgcn_sched_barrier(0); }
+                    if (!GEN_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc[2 * (g & 3) + jj][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[g % 3][jj], bq[g >> 2][n],
+                                                                                             acc[2 * (g & 3) + jj][n], 0, 0, 0);
+                    if (!GEN_PRIO) __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                continue;
+            }
+            if (k + 1 < nk) stage(k + 1, (k + 1) & 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int fo = ks ? foff1 : foff0;
