@@ -73,10 +73,11 @@ def per_layer(d):
     lf = os.path.join(d, "layers.txt")
     if not os.path.isfile(lf):
         return
-    names = [l.strip() for l in open(lf) if l.strip()]
+    # (the shared-buffer workspace layout adds border-zeroing launches, several per profile entry: left out on both sides)
+    names = [l.strip() for l in open(lf) if l.strip() and not l.startswith("zero_borders")]
 
     def engine_rows(path, key_start, key_end):
-        rows = [r for r in csv.DictReader(open(path)) if "hctr" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(path)) if "hctr" in r["Kernel_Name"] and "zero_borders" not in r["Kernel_Name"]]
         rows.sort(key=lambda r: int(r[key_start]))
         return rows
 
@@ -90,14 +91,15 @@ def per_layer(d):
     for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         files = glob.glob(os.path.join(d, "pmc_" + kind, "*", "*_counter_collection.csv"))
         if files:
-            rows = [r for r in csv.DictReader(open(files[0])) if "hctr" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+            rows = [r for r in csv.DictReader(open(files[0])) if "hctr" in r["Kernel_Name"] and r["Counter_Name"] == ctr
+                    and "zero_borders" not in r["Kernel_Name"]]
             rows.sort(key=lambda r: int(r["Dispatch_Id"]))
             pm[kind] = rows[-n:] if len(rows) >= n else None
     # matrix-pipe pass: busy = SQ_VALU_MFMA_BUSY_CYCLES / (128 * GRBM_GUI_ACTIVE), clock = GRBM_GUI_ACTIVE / 8 / time
     mfma = {}
     files = glob.glob(os.path.join(d, "pmc_mfma", "*", "*_counter_collection.csv"))
     if files:
-        allrows = [r for r in csv.DictReader(open(files[0])) if "hctr" in r["Kernel_Name"]]
+        allrows = [r for r in csv.DictReader(open(files[0])) if "hctr" in r["Kernel_Name"] and "zero_borders" not in r["Kernel_Name"]]
         for ctr in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
             rows = [r for r in allrows if r["Counter_Name"] == ctr]
             rows.sort(key=lambda r: int(r["Dispatch_Id"]))

@@ -1,14 +1,14 @@
 """Per-layer SQ counter table from tools/profile_sq.sh output (last step of the run)."""
 import collections, csv, glob, os, sys
 d = sys.argv[1]
-names = [l.strip() for l in open(os.path.join(d, "layers.txt")) if l.strip()]
+names = [l.strip() for l in open(os.path.join(d, "layers.txt")) if l.strip() and not l.startswith("zero_borders")]
 n = len(names)
 want = sys.argv[2].split(",") if len(sys.argv) > 2 else None
 for sub in ("a", "b"):
     files = glob.glob(os.path.join(d, sub, "*", "*_counter_collection.csv"))
     if not files:
         continue
-    rows = [r for r in csv.DictReader(open(files[0])) if "hctr" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(files[0])) if "hctr" in r["Kernel_Name"] and "zero_borders" not in r["Kernel_Name"]]
     per = collections.OrderedDict()
     for r in rows:
         per.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
