@@ -1351,7 +1351,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                     // next tile's first step (persistent variant only).
                     // nothing to stage on the very last step: no DMA is then in flight when the epilogue
                     // starts, so the workgroup can retire without waiting for its output stores
-                    if ((DMA_SPREAD == 0 || DMA_SPREAD == 3) && (more || has_next)) stage_weights(wsrc, kc1, tap1, (kbase + k + 1) & 1);
+                    if ((DMA_SPREAD == 0 || DMA_SPREAD == 3) && (more || has_next) && !(a.dbg & 512))    // dbg 512: no weight DMA
+                        stage_weights(wsrc, kc1, tap1, (kbase + k + 1) & 1);
                     if (rtouch && k == ktouch) {
                         const int prow = GEOM ? (tid >> 5) : (tid >> 4), pcol = GEOM ? (tid & 31) : (tid & 15);
                         const char* rp = (const char*)(a.resid + a.out_off + cur.img * a.out_sb +
