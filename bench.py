@@ -218,6 +218,9 @@ def parse_args():
                     help="synthetic checkpoint: near-tie-rich random head (default) or the trained-like head")
     ap.add_argument("--no-pipeline", action="store_true", help="c5: run front end and host search back to back")
     ap.add_argument("--chunk", type=int, default=64, help="c5: lines per pipeline chunk (the last chunks taper to 16)")
+    ap.add_argument("--no-oracle-check", action="store_true",
+                    help="c5: skip the oracle codec check of all beam strings (profiling runs: the worker pool must not be "
+                         "used under rocprofv3, whose preloaded library has touched the GPU before the pool was forked)")
     ap.add_argument("--extra-steps", type=int, default=2, help="timed steps of the configs[2] / configs[4] records")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"],
                     help="c2 (default, the driver's line): B=64 x W=2000 greedy at 1 GPU (+ the c3 / c5 records), configs[3] "
@@ -646,6 +649,8 @@ def run_c5(args, hctr_amd, model, dev, host, steps, warmup, pool):
     res["pipelined_equals_sequential"] = bool(out == out_seq)
     # parity of ALL lines: the oracle codec (CPU restatement of the reference's prefix beam search) on the ENGINE's device
     # top-k / log-probs must give the same strings (worker pool, outside the timed region)
+    if args.no_oracle_check:
+        return res
     fe = fe_keep[0]
     log("configs[4]: checking all %d beam strings with the oracle codec on the engine's top-k ..." % n_lines)
     t0 = time.perf_counter()
