@@ -109,6 +109,24 @@ __device__ __forceinline__ void glds16_asm_s(const char* sbase, uint32_t voff, c
                  : "memory");
 }
 
+// Four pieces of one wave in ONE asm statement: same per-lane offset, four wave-uniform bases, four LDS addresses; M0 is
+// saved and restored once instead of four times (six scalar moves fewer per K step).
+__device__ __forceinline__ void glds16x4_asm_s(const char* s0, const char* s1, const char* s2, const char* s3, uint32_t voff,
+                                               char* d0, char* d1, char* d2, char* d3) {
+    const uint32_t l0 = (uint32_t)(uintptr_t)((lptr_t)d0), l1 = (uint32_t)(uintptr_t)((lptr_t)d1);
+    const uint32_t l2 = (uint32_t)(uintptr_t)((lptr_t)d2), l3 = (uint32_t)(uintptr_t)((lptr_t)d3);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+                 "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(l0), "s"(l1), "s"(l2), "s"(l3)
+                 : "memory");
+}
+
 // -------------------------------------------------------------------------------------------
 // Shared epilogue of the MFMA conv kernels: + folded-BN bias, optional SE partial sums, ReLU,
 // (2,1) max-pool, zeroing of columns >= W, fp16 NHWC store (or fp32 rows in linear mode).
@@ -1038,6 +1056,20 @@ constexpr int kHalo4Lds = 2 * 16384 + kHaloBytes;          // 78848
 // pre-phase of conv2's K loop instead of as its own launch: acc = Wd * x over the block input's channels (centre
 // tap of x's halo), then acc <- (acc + bd) / s + b2, then the 3x3 taps of conv2 accumulate on top and the epilogue
 // multiplies by s: s * (W2*t + b2) + (Wd*x + bd). The residual is neither written nor read back (4.2 GB per launch).
+#ifndef LEAN
+#define LEAN 1         // K loop with its nine taps unrolled (tap / row / parity arithmetic and the step's branches fold into
+                       // constants), ONE per-lane weight offset (the piece stride moves into the scalar base) and one M0
+                       // save / restore per four pieces. -DLEAN=0: the rolled loop of rounds 1-3 (A/B, bit-identical).
+#endif
+#ifndef BPRE
+#define BPRE 1         // (with LEAN) next tap's first pixel fragments are read during the current step, see mma_step
+#endif
+#ifndef BPRE_AT
+#define BPRE_AT 4      // ... behind the MFMAs of this group (4..7)
+#endif
+#ifndef RTOUCH
+#define RTOUCH 0       // residual pre-touch experiment (HCTR_RTOUCH=1 needs -DRTOUCH=1; measured neutral, see below)
+#endif
 template <int GEOM, bool SPLIT, bool PERSIST, bool STAMP = false, bool DSFUSE = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a) {
     static_assert(!DSFUSE || !PERSIST, "downsample fusion: non-persistent instances only");
@@ -1111,6 +1143,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     const int wrow = GEOM ? (wm >> 1) * 4 : wm * 4;               // this wave's 4 x 16 patch inside the tile
     const int wcol = GEOM ? (wm & 1) * 16 : 0;
     uint32_t woff[4], hoff[12];
+    // BPRE: the twelve halo offsets are not kept through the K loop (bq[0] now lives across the step boundary and the loop
+    // would spill - a reload in front of a DMA drains vmcnt). Six registers hold the pieces' (hy, hx) pairs instead, and
+    // the offsets are rebuilt during tap 8's last four MFMA groups, where bq[0] is free.
+    uint32_t hpk[6], hcp16 = 0;
     const int q = lane >> 4, c = lane & 15;
     const int aoff0 = c * 128 + (((0 + q) ^ (lane & 7)) << 4);
     const int aoff1 = c * 128 + (((4 + q) ^ (lane & 7)) << 4);
@@ -1118,6 +1154,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     auto stage_w = [&](const char* wb, int rowcin, const uint32_t (&wo)[4], int kc, int tap, int buf) {
         const char* src = wb + ((int64_t)tap * a.CoutPad * rowcin + (int64_t)kc * kBK) * 2;
         char* dst = smem + buf * 16384 + (wv * 4) * 1024;
+        if (LEAN) {                                          // piece i = 8 cout rows further on: same lane offset, scalar stride
+            const int64_t ps = (int64_t)rowcin * 16;
+            glds16x4_asm_s(src, src + ps, src + 2 * ps, src + 3 * ps, wo[0], dst, dst + 1024, dst + 2048, dst + 3072);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16_asm_s(src, wo[i], dst + i * 1024);
     };
@@ -1152,11 +1193,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             if (hx > TC + 1) hx = TC + 1;                       // pad columns: any valid address
             if (hy > TR + 1) hy = TR + 1;                       // pieces >= 45 are never issued
             hoff[r] = ((uint32_t)hy * (uint32_t)in_sh + (uint32_t)hx * (uint32_t)rowcin) * 2u + cp * 16;
+            hcp16 = cp * 16;                                    // (row & 7 does not depend on r: pieces are 32 rows apart)
+            const uint32_t pk = (uint32_t)hy << 8 | (uint32_t)hx;
+            if (r & 1) hpk[r >> 1] |= pk << 16;
+            else hpk[r >> 1] = pk;
+        }
+    };
+    // offsets of pieces r0 .. r0+2 back from the packed coordinates
+    auto unpack_hoff = [&](int r0, uint32_t insh2, uint32_t cin2) {
+#pragma unroll
+        for (int r = r0; r < r0 + 3; ++r) {
+            const uint32_t pk = hpk[r >> 1] >> ((r & 1) * 16);
+            hoff[r] = ((pk >> 8) & 0xff) * insh2 + (pk & 0xff) * cin2 + hcp16;
         }
     };
     const int hbuf = 32768 + wrow * (S * 128);
     // fragment addresses of a tap inside the halo image
+    // LEAN: all 18 (tap, even / odd) fragment addresses are six per-lane values (dx = -1, 0, 1; swizzle parity) plus
+    // constants - spelled out so that the unrolled loop keeps six address registers, not one or two per tap
+    int bx[3][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int u = wcol + c + d;
+        const int v0 = u * 128 + (((q ^ (u & 7)) & 7) << 4);
+        bx[d][0] = hbuf + v0;
+        bx[d][1] = hbuf + (v0 ^ 64);
+    }
     auto b_ptrs = [&](int tap, const char*& be, const char*& bo) {
+        if (LEAN) {
+            const int tdy = tap / 3, d = tap - tdy * 3;
+            be = smem + bx[d][tdy & 1] + tdy * (S * 128);
+            bo = smem + bx[d][(tdy & 1) ^ 1] + tdy * (S * 128);
+            return;
+        }
         const int tdy = tap / 3, dx = tap - tdy * 3 - 1;
         const int u = wcol + c + 1 + dx;
         const int v0 = u * 128 + (((q ^ (u & 7) ^ ((tdy & 1) << 2)) & 7) << 4);
@@ -1187,9 +1256,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         // Rolling fragment pipeline: 8 groups of 8 MFMAs (2 A fragments x 4 B fragments); A pairs are read two
         // groups ahead into a 3-slot ring, the second half's B fragments during group 1; `stage_next` issues the
         // next step's weight DMA after the first reads so its issue cost overlaps their LDS latency.
+        // BPRE (LEAN only): the pixel fragments of the NEXT tap's first half are read during this step's groups 4-7 into
+        // bq[0] (dead after group 3) - the halo does not change inside a chunk - so only weight fragments are read between
+        // the barrier and the first MFMA. `have_b0`: bq[0] was filled that way by the previous step; `nbe`: != nullptr ->
+        // prefetch from (nbe, nbo).
+        f16x8 bq[2][4];
         auto mma_step = [&](const char* wt, const char* be, const char* bo, auto&& stage_next, auto&& stage_piece,
-                            auto&& after_group) {
-            f16x8 ar[RING][2], bq[2][4];
+                            auto&& after_group, bool have_b0 = false, const char* nbe = nullptr, const char* nbo = nullptr) {
+            f16x8 ar[RING][2];
             auto read_a = [&](int g, f16x8 (&dst)[2]) {
                 const int ks = g >> 2, jp = g & 3;
                 const char* base = wt + (ks ? aoff1 : aoff0);
@@ -1203,7 +1277,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             };
             __builtin_amdgcn_sched_barrier(0);
             if (DMA_SPREAD == 3) { stage_next(); __builtin_amdgcn_sched_barrier(0); }      // (A/B: DMA before the first reads)
-            read_b(0, bq[0]);
+            if (!have_b0) read_b(0, bq[0]);
             read_a(0, ar[0]);
             __builtin_amdgcn_sched_barrier(0);
             read_a(1, ar[1]);
@@ -1229,6 +1303,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 if (PRIO_MODE == 2) __builtin_amdgcn_s_setprio(1);
                 if (DMA_SPREAD == 1 && g < 4) stage_piece(g);
                 if (DMA_SPREAD == 2 && (g & 1) == 0) stage_piece(g >> 1);
+                if (g == BPRE_AT && nbe != nullptr) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) bq[0][n] = *(const f16x8*)(((n & 1) ? nbo : nbe) + n * (S * 128));
+                }
                 after_group(g);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1320,7 +1398,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         // wait leaves them in flight). Measured (profiles/r03_overhead_experiments.txt): the epilogue's residual phase
         // drops 3.6 -> 2.7 us, the K loop grows by as much, the step time is unchanged - the phase is the latency of 16
         // dependent-free loads through a busy memory pipeline, not an HBM miss.
-        const bool rtouch = !SPLIT && !DSFUSE && a.rtouch && a.resid != nullptr && nk >= 6;
+        const bool rtouch = RTOUCH && !SPLIT && !DSFUSE && a.rtouch && a.resid != nullptr && nk >= 6;
         const int ktouch = nk - 3;
         // residual prefetch during the last K step (f16, identity blocks; a.rpre: A/B switch HCTR_RPRE)
         const bool rpre = RPRE && !SPLIT && !DSFUSE && !PERSIST && a.rpre && a.resid != nullptr && a.se_scale != nullptr && nk >= 1;
@@ -1332,7 +1410,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             // with the residual prefetch the very last K step (tap 8 of the last chunk) runs after this loop, where the
             // loop's per-lane DMA offsets are dead and their registers can hold the residual
             const int ntap = (rpre && !next_chunk) ? 8 : 9;
+#if LEAN
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
             for (int tap = 0; tap < ntap; ++tap) {
                 const int k = kc * 9 + tap;
                 if (rtouch && k == ktouch + 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -1346,6 +1428,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 const int tap1 = more ? (wrap ? 0 : tap + 1) : 0;
                 const int kc1 = more ? (wrap ? kc + 1 : kc) : 0;
                 const char* wsrc = more ? cur.wb : nwb;
+                const bool bpre = LEAN && BPRE && !DSFUSE && !SPLIT && !PERSIST;      // (the others would spill)
+                const char *nbe = nullptr, *nbo = nullptr;
+                if (bpre && tap < 8) b_ptrs(tap + 1, nbe, nbo);
                 mma_step(smem + ((kbase + k) & 1) * 16384, be, bo, [&] {
                     // the next K step's weights into the other buffer; on a tile's last step that is the
                     // next tile's first step (persistent variant only).
@@ -1364,7 +1449,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                     }
                 }, [&](int i) {
                     if (more || has_next) stage_weights_piece(wsrc, kc1, tap1, (kbase + k + 1) & 1, i);
-                }, [&](int) {});
+                }, [&](int g) {
+                    if (bpre && tap == 8 && g >= 4) unpack_hoff(3 * (g - 4), (uint32_t)a.in_sh * 2u, (uint32_t)cin * 2u);
+                }, bpre && tap > 0, nbe, nbo);
             }
             if ((next_chunk || has_next) && !(a.dbg & 32)) {     // dbg 32: timing experiment without the reload
                 // single halo buffer: every wave has consumed its last B fragments of this chunk (they fed
@@ -1441,6 +1528,201 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     }
 }
 
+// -------------------------------------------------------------------------------------------
+// conv3x3_halo4h: the halo4 kernel with the halo held as TWO 32-channel halves (64-byte LDS rows) so that it is
+// effectively double-buffered without more LDS. halo4 keeps one 64-channel halo and must stop at every chunk boundary:
+// barrier, 12 DMA pieces per wave, wait for them (5.5 % of its K loop, profiles/r03_overhead_experiments.txt). Here a
+// chunk's 18 (tap, half) units run as half A's nine taps, then half B's; two units (64 MFMAs per wave) per step:
+//   step 0..3: (A0,A1) (A2,A3) (A4,A5) (A6,A7)   step 4: (A8,B0)   step 5..8: (B1,B2) (B3,B4) (B5,B6) (B7,B8)
+// Half A is last read in step 4, half B in step 8, so the NEXT chunk's half A streams in during steps 5-7 and a chunk's
+// own half B during its steps 0-2 (two pieces per wave and step, issued behind the step's weight pieces, so the next
+// step's counted wait leaves them in flight): no extra barrier, no stall, the same number of DMA pieces.
+// LDS rows are 64 B (32 channels): a 16x16x32 operand fragment is 16 rows x 64 B = 1 KiB; the 16-byte slot of chunk q in
+// row r is q ^ 2*((r >> 2) & 1), conflict-free for ds_read_b128 at every row alignment (checked exhaustively against the
+// instruction's 4 x 16 lane groups). Weight step buffer = 2 units x [128 couts][32 cin] = 16 KB, double-buffered.
+// f16 only, non-persistent, no fused downsample (those launches stay on halo4).
+// -------------------------------------------------------------------------------------------
+template <int GEOM>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo4h_kernel(const ConvArgs a) {
+    constexpr int WN = 1, WM = 4, JT = 8, BN = 128;
+    constexpr int TR = GEOM ? 8 : 16, TC = GEOM ? 32 : 16;
+    constexpr int S = TC + 4;
+    constexpr int kHalf = (TR + 2) * S * 64;                  // bytes of one 32-channel halo half (23040)
+    constexpr int kHalfPieces = (kHalf + 1023) / 1024;        // 23 one-KiB pieces, the last one half full
+    static_assert(2 * kHalf == kHaloBytes && kHalfPieces == 23, "halo footprint");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv;
+    const int cin = a.Cin;
+    const int nkc = cin / kBK;
+    {
+        const int k0 = a.mtiles, k1 = a.ntiles, k2 = a.tilesW, k3 = a.tilesH, k4 = a.Cin, k5 = a.in_sh, k6 = a.nt_shift,
+                  k7 = a.th_shift, k8 = a.CoutPad;
+        const uint64_t k9 = a.tw_magic;
+        const int64_t k10 = a.in_sb;
+        const half_t *k11 = a.x, *k12 = a.w;
+        const float* k13 = a.bias;
+        asm volatile("" ::"s"(k0), "s"(k1), "s"(k2), "s"(k3), "s"(k4), "s"(k5), "s"(k6), "s"(k7), "s"(k8), "s"(k9), "s"(k10),
+                     "s"(k11), "s"(k12), "s"(k13));
+    }
+    const int total = a.mtiles * a.ntiles;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tq = total >> 3, tr = total & 7;
+    const int lin = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq) + local;
+    int nt, mt, t2, th, img;
+    if (a.nt_shift >= 0) { nt = lin & (a.ntiles - 1); mt = lin >> a.nt_shift; }
+    else { nt = lin % a.ntiles; mt = lin / a.ntiles; }
+    const int n0 = nt * BN;
+    t2 = (int)(((uint64_t)(uint32_t)mt * a.tw_magic) >> 40);
+    const int tw = mt - t2 * a.tilesW;
+    if (a.th_shift >= 0) { th = t2 & (a.tilesH - 1); img = t2 >> a.th_shift; }
+    else { th = t2 % a.tilesH; img = t2 / a.tilesH; }
+    const char* xb = (const char*)(a.x + img * a.in_sb + (int64_t)(th * TR) * a.in_sh + (int64_t)(tw * TC) * cin);
+    const char* wb = (const char*)(a.w + (int64_t)n0 * cin);
+
+    const int wrow = GEOM ? (wm >> 1) * 4 : wm * 4;
+    const int wcol = GEOM ? (wm & 1) * 16 : 0;
+    const int q = lane >> 4, c = lane & 15;
+    // ---- per-lane DMA offsets: a piece is 16 LDS rows x 64 B; lane l fills slot l & 3 of row l >> 2 ----
+    // Weights: piece i of a wave is 16 cout rows further on (the swizzle key (row >> 2) & 1 does not change), so ONE lane
+    // offset serves all four and the piece stride goes into the scalar base. Halo: a piece's pixel -> (hy, hx) needs a
+    // division, six of them held in registers spill (the K loop is fully unrolled, 128 accumulators + 56 fragment
+    // registers live) and a spill reload drains vmcnt; they are recomputed at the issue point instead (a dozen VALU
+    // instructions per piece in the shadow of the MFMAs) from an opaque copy of the lane id so the compiler cannot
+    // hoist them back out of the loop.
+    uint32_t woff0;
+    {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int prow = ln >> 2, slot = ln & 3;
+        const int row = ((wv * 4) & 7) * 16 + prow;             // cout row inside the unit's [128][32] tile
+        woff0 = (uint32_t)row * (uint32_t)cin * 2u + (uint32_t)((slot ^ (((row >> 2) & 1) << 1)) << 4);
+    }
+    const int wpiece = 16 * cin * 2;                            // bytes between a wave's weight pieces
+    // weights of step s of chunk kc (units 2s, 2s+1) into buffer buf: waves 0,1 stage the first unit, 2,3 the second
+    auto stage_w = [&](int kc, int s, int buf) {
+        const int u = 2 * s + (wv >> 1);
+        const int tap = u < 9 ? u : u - 9, half = u < 9 ? 0 : 1;
+        const char* src = wb + ((int64_t)tap * a.CoutPad * cin + (int64_t)kc * kBK + half * 32) * 2;
+        char* dst = smem + buf * 16384 + (wv * 4) * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_asm_s(src + i * wpiece, woff0, dst + i * 1024);
+    };
+    // pieces r0, r0+1 (of this wave's six; piece wv + 4r, the 24th slot repeats piece 22) of half `half` of chunk kc
+    auto stage_h2 = [&](int kc, int half, int r0) {
+        const char* src = xb + ((int64_t)kc * kBK + half * 32) * 2;
+        char* dst = smem + 32768 + half * kHalf;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int prow = ln >> 2, slot = ln & 3;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = r0 + rr;
+            int hp = wv + 4 * r;
+            if (hp > kHalfPieces - 1) hp = kHalfPieces - 1;
+            const int hr = hp * 16 + prow;                      // halo pixel index hy * S + hx
+            int hy = (int)(((uint32_t)hr * (65536u / S + 1u)) >> 16), hx = hr - hy * S;      // hr < 512: exact
+            if (hx > TC + 1) hx = TC + 1;                       // pad columns: any valid address
+            if (hy > TR + 1) hy = TR + 1;                       // rows past the halo (second half of the last piece): masked
+            const uint32_t off = ((uint32_t)hy * (uint32_t)a.in_sh + (uint32_t)hx * (uint32_t)cin) * 2u +
+                                 (uint32_t)((slot ^ (((hr >> 2) & 1) << 1)) << 4);
+            if (hp == kHalfPieces - 1) {                        // the last piece covers only 8 rows: upper lanes stay out
+                if (lane < 32) glds16_asm_s(src, off, dst + hp * 1024);
+            } else {
+                glds16_asm_s(src, off, dst + hp * 1024);
+            }
+        }
+    };
+    const int aoff = c * 64 + ((q ^ (((c >> 2) & 1) << 1)) << 4);
+
+    // prologue: half A of chunk 0 (all six pieces of every wave) and the weights of step 0
+    stage_h2(0, 0, 0);
+    stage_h2(0, 0, 2);
+    stage_h2(0, 0, 4);
+    stage_w(0, 0, 0);
+    f32x4 acc[JT][4];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const f32x4 b4 = *(const f32x4*)(a.bias + n0 + q * 8 + acc_cout_offset(j));
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[j][n] = b4;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_setprio(1);
+    int gstep = 0;
+    bool halo_prev = false;
+    for (int kc = 0; kc < nkc; ++kc) {
+        const bool next_chunk = kc + 1 < nkc;
+#pragma unroll
+        for (int s = 0; s < 9; ++s, ++gstep) {               // fully unrolled: taps, halves and piece indices are constants
+            if (halo_prev) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // the two halo pieces of the last step may fly on
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // fragment addresses of the step's two units
+            const char* wt = smem + (gstep & 1) * 16384 + aoff;
+            const char *be[2], *bo[2];
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) {
+                const int u = 2 * s + uu;
+                const int tap = u < 9 ? u : u - 9, half = u < 9 ? 0 : 1;
+                const int tdy = tap / 3, dx = tap - tdy * 3 - 1;
+                const int hr0 = (wrow + tdy) * S + wcol + c + 1 + dx;           // halo pixel of pixel-repeat n = 0
+                const char* hb = smem + 32768 + half * kHalf + hr0 * 64;
+                const int slot = q ^ (((hr0 >> 2) & 1) << 1);
+                be[uu] = hb + (slot << 4);                                      // even n (S / 4 is odd: the key flips with n)
+                bo[uu] = hb + ((slot ^ 2) << 4);
+            }
+            const bool more = !(s == 8 && !next_chunk);
+            const bool halo_now = (s < 3) || (next_chunk && s >= 5 && s < 8);
+            f16x8 ar[3][2], bq[2][4];
+            auto read_a = [&](int g, f16x8 (&dst)[2]) {
+                const char* base = wt + (g >> 2) * 8192 + (2 * (g & 3)) * 1024;
+                dst[0] = *(const f16x8*)base;
+                dst[1] = *(const f16x8*)(base + 1024);
+            };
+            auto read_b = [&](int uu, f16x8 (&dst)[4]) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) dst[n] = *(const f16x8*)(((n & 1) ? bo[uu] : be[uu]) + n * (S * 64));
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            read_b(0, bq[0]);
+            read_a(0, ar[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(1, ar[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                const int s1 = s == 8 ? 0 : s + 1, kc1 = s == 8 ? kc + 1 : kc;
+                stage_w(kc1, s1, (gstep + 1) & 1);
+            }
+            if (halo_now) {
+                if (s < 3) stage_h2(kc, 1, 2 * s);                   // this chunk's half B (first read in step 4)
+                else stage_h2(kc + 1, 0, 2 * (s - 5));               // the next chunk's half A (half A was last read in step 4)
+            }
+            halo_prev = halo_now;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (g + 2 < 8) read_a(g + 2, ar[(g + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g == 1) { read_b(1, bq[1]); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[2 * (g & 3) + jj][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[g % 3][jj], bq[g >> 2][n],
+                                                                                         acc[2 * (g & 3) + jj][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    conv_epilogue<WN, WM, JT, false, false, true, true, false>(a, acc, smem + kHalo4Lds, tid, lane, 0, wm, n0, mt, img, th, tw,
+                                                               th * TR + wrow, tw * TC + wcol);
+}
+
 #ifndef LDS_PAD
 #define LDS_PAD 0      // A/B build switch: extra LDS bytes per workgroup (e.g. 40000 forces ONE workgroup per CU)
 #endif
@@ -1509,6 +1791,18 @@ static hipError_t launch_conv_halo4(const ConvArgs& a0, hipStream_t s) {
     a.th_shift = shift_of(a.tilesH);
     if (a.tilesW < 1 || (uint64_t)a.mtiles * (uint64_t)a.tilesW >= ((uint64_t)1 << 40)) return hipErrorInvalidValue;
     a.tw_magic = (((uint64_t)1 << 40) + (uint64_t)a.tilesW - 1) / (uint64_t)a.tilesW;
+    // HCTR_HALFHALO=1: the half-buffered halo variant for the plain f16 launches (A/B)
+    static const bool halfhalo = [] { const char* e = getenv("HCTR_HALFHALO"); return e ? atoi(e) != 0 : false; }();
+    static const int persist = [] { const char* e = getenv("HCTR_PERSIST"); return e ? atoi(e) : 0; }();
+    if (halfhalo && !a.split && a.ds_x == nullptr && a.stamps == nullptr && persist == 0 && a.Cin % kBK == 0) {
+        static bool done[64] = {};
+        hipError_t e0 = raise_lds_limit((const void*)conv3x3_halo4h_kernel<GEOM>, kHalo4LdsTotal, done);
+        if (e0 != hipSuccess) return e0;
+        static const int dbg = env_dbg();
+        a.dbg |= dbg;
+        hipLaunchKernelGGL((conv3x3_halo4h_kernel<GEOM>), dim3(a.mtiles * a.ntiles), dim3(256), kHalo4LdsTotal, s, a);
+        return hipGetLastError();
+    }
     return a.split ? launch_conv_halo4_t<GEOM, true>(a, s) : launch_conv_halo4_t<GEOM, false>(a, s);
 }
 
