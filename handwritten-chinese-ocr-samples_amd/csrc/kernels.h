@@ -89,7 +89,7 @@ struct ConvArgs {
     unsigned long long* stamps;   // diagnostic instance only (hctr_debug_stamps): 16 x u64 per workgroup, else NULL
     // timing experiments only (HCTR_DBG), results INVALID. 8-wave/generic kernels: 1 = DMA from fixed hot addresses,
     // 2 = no DMA in the loop. halo4 kernel, bit mask: 32 = no halo reload at chunk boundaries, 64 = no K loop,
-    // 128 = no epilogue, 256 = no output stores, 512 = no weight DMA inside the K loop.
+    // 128 = no epilogue, 256 = no output stores, 512 = no weight DMA inside the K loop, 1024 = no per-step barrier.
     int dbg;
 };
 

@@ -448,3 +448,37 @@ def test_beam_pipeline_chunk_schedule(pkg):
         assert sum(h - l for l, h in sp) == n and all(0 < h - l <= c for l, h in sp)
         assert all(a[1] == b[0] for a, b in zip(sp, sp[1:])) and (not sp or (sp[0][0] == 0 and sp[-1][1] == n))
     assert [h - l for l, h in pipe.chunk_schedule(256, 64)] == [64, 64, 64, 32, 16, 16]
+
+
+def test_hot_kernels_do_not_spill(pkg, tmp_path):
+    """The K loops of the hot kernels must not spill: a spill reload in front of an LDS-DMA drains vmcnt and serialises
+    the loop. The 3x3 kernel sits at the 256-register limit, where an innocent edit flips the
+    allocator - so the built library's own metadata is checked: no spilled vector register and no private segment for
+    the instances the f16 forward pass launches (3x3 halo kernel both tile geometries + fused downsample, fused stem,
+    head GEMM)."""
+    import shutil
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(llvm + "/llvm-objdump") and os.path.exists(llvm + "/llvm-readelf")):
+        pytest.skip("llvm-objdump / llvm-readelf not found")
+    lib = tmp_path / "lib.so"
+    shutil.copy(pkg.build(), lib)
+    subprocess.run([llvm + "/llvm-objdump", "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    meta = {}
+    for co in tmp_path.glob("lib.so.*gfx950"):
+        notes = subprocess.run([llvm + "/llvm-readelf", "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+        cur = None
+        for line in notes.splitlines():
+            m = re.match(r"\s*\.(name|private_segment_fixed_size|vgpr_spill_count|vgpr_count):\s+(\S+)", line)
+            if not m:
+                continue
+            if m.group(1) == "name":
+                cur = meta.setdefault(m.group(2), {})
+            elif cur is not None:
+                cur[m.group(1)] = int(m.group(2))
+    hot = ["conv3x3_halo4_kernelILi0ELb0ELb0ELb0ELb0E", "conv3x3_halo4_kernelILi1ELb0ELb0ELb0ELb0E",
+           "conv3x3_halo4_kernelILi0ELb0ELb0ELb0ELb1E", "stem_conv0_2_kernel", "conv_mfma_kernelILi2ELi4ELi8ELi1ELb1E"]
+    for h in hot:
+        names = [n for n in meta if h in n]
+        assert names, h
+        for n in names:
+            assert meta[n]["vgpr_spill_count"] == 0 and meta[n]["private_segment_fixed_size"] == 0, (n, meta[n])
