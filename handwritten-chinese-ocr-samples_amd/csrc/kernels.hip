@@ -1067,12 +1067,22 @@ constexpr int kHalo4Lds = 2 * 16384 + kHaloBytes;          // 78848
 #ifndef BPRE_AT
 #define BPRE_AT 4      // ... behind the MFMAs of this group (4..7)
 #endif
+#ifndef RESPRE_BPRE
+#define RESPRE_BPRE 0  // BPRE in the residual-in-prologue instances too (spills eight halo offsets as of this writing)
+#endif
 #ifndef RTOUCH
 #define RTOUCH 0       // residual pre-touch experiment (HCTR_RTOUCH=1 needs -DRTOUCH=1; measured neutral, see below)
 #endif
-template <int GEOM, bool SPLIT, bool PERSIST, bool STAMP = false, bool DSFUSE = false>
+// RESPRE: conv2 of an identity block (BasicBlock :54-58, out = relu(o * s + x)). The SE scale s is known before conv2 runs
+// (se_premean), so the residual x is fetched in the PROLOGUE - its HBM round trip overlaps the first operands' DMA wait -
+// and the accumulators start at x / max(s, floor) + bias; the epilogue multiplies by max(s, floor), exactly what the
+// fused downsample does with its 1x1 branch. The epilogue's residual phase (16 loads per lane issued behind the partner
+// workgroup's DMA stream: 4.5 of its 7.6 us, profiles/r03_lean_workgroup_phases_*) disappears - and reappears in the
+// prologue: measured slower as a whole (see launch_conv_halo4_t), kept as an opt-in experiment.
+template <int GEOM, bool SPLIT, bool PERSIST, bool STAMP = false, bool DSFUSE = false, bool RESPRE = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a) {
     static_assert(!DSFUSE || !PERSIST, "downsample fusion: non-persistent instances only");
+    static_assert(!RESPRE || (!DSFUSE && !PERSIST && !SPLIT), "residual-in-prologue: plain f16 instances only");
     constexpr int WN = 1, WM = 4, JT = 8, BN = 128;
     constexpr int TR = GEOM ? 8 : 16, TC = GEOM ? 32 : 16;       // tile rows / columns
     constexpr int S = TC + 4;                                      // halo row stride in pixels
@@ -1382,12 +1392,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                     stamp(2);
                 }
             }
-            // accumulators start at the folded-BN bias (its load hides behind the first operands' DMA)
+            if (RESPRE) {
+                // accumulators start at residual / max(s, floor) + bias (element order as in conv_epilogue's residual branch)
+                const int w = cur.tw * TC + wcol + c;
+                const bool wok = w < a.out_wlimit;
+                const half_t* rb = a.resid + a.out_off + cur.img * a.out_sb + (int64_t)w * a.out_sw + cur.n0 + q * 8 +
+                                   (int64_t)(cur.th * TR + wrow) * a.out_sh;
+                const float* sc = a.se_scale + (int64_t)cur.img * a.Cout + cur.n0 + q * 8;
+                f16x8 rlo[JT / 4][4], rhi[JT / 4][4];
 #pragma unroll
-            for (int j = 0; j < JT; ++j) {
-                const f32x4 b4 = *(const f32x4*)(a.bias + cur.n0 + q * 8 + acc_cout_offset(j));
+                for (int cb = 0; cb < JT / 4; ++cb)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[j][n] = b4;
+                    for (int n = 0; n < 4; ++n) {
+                        const half_t* r = rb + (int64_t)n * a.out_sh + cb * 64;
+                        rlo[cb][n] = wok ? *(const f16x8*)r : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                        rhi[cb][n] = wok ? *(const f16x8*)(r + 32) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    }
+#pragma unroll
+                for (int j = 0; j < JT; ++j) {
+                    const f32x4 b4 = *(const f32x4*)(a.bias + cur.n0 + q * 8 + acc_cout_offset(j));
+                    const f32x4 s4 = *(const f32x4*)(sc + acc_cout_offset(j));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float inv = __builtin_amdgcn_rcpf(fmaxf(s4[i], kSeScaleFloor));
+                        const int e = (j & 3) * 4 + i;
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            const float r = e < 8 ? (float)rlo[j >> 2][n][e] : (float)rhi[j >> 2][n][e - 8];
+                            acc[j][n][i] = fmaf(r, inv, b4[i]);
+                        }
+                    }
+                }
+            } else {
+                // accumulators start at the folded-BN bias (its load hides behind the first operands' DMA)
+#pragma unroll
+                for (int j = 0; j < JT; ++j) {
+                    const f32x4 b4 = *(const f32x4*)(a.bias + cur.n0 + q * 8 + acc_cout_offset(j));
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[j][n] = b4;
+                }
             }
         }
 
@@ -1431,7 +1474,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 const int tap1 = more ? (wrap ? 0 : tap + 1) : 0;
                 const int kc1 = more ? (wrap ? kc + 1 : kc) : 0;
                 const char* wsrc = more ? cur.wb : nwb;
-                const bool bpre = LEAN && BPRE && !DSFUSE && !SPLIT && !PERSIST;      // (the others would spill)
+                const bool bpre = LEAN && BPRE && !DSFUSE && !SPLIT && !PERSIST && !(RESPRE && !RESPRE_BPRE);      // (the others would spill)
                 const char *nbe = nullptr, *nbo = nullptr;
                 if (bpre && tap < 8) b_ptrs(tap + 1, nbe, nbo);
                 mma_step(smem + ((kbase + k) & 1) * 16384, be, bo, [&] {
@@ -1501,7 +1544,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         } else
         {
             const int tw = cur.tw, th = cur.th, img = cur.img;
-            conv_epilogue<WN, WM, JT, false, SPLIT, true, true, DSFUSE>(a, acc, smem + kHalo4Lds, tid, lane, 0, wm, cur.n0, cur.mt,
+            conv_epilogue<WN, WM, JT, false, SPLIT, true, true, DSFUSE || RESPRE>(a, acc, smem + kHalo4Lds, tid, lane, 0, wm, cur.n0, cur.mt,
                                                           img, th, tw, th * TR + wrow, tw * TC + wcol,
                                                           STAMP ? a.stamps + (size_t)blockIdx.x * 16 : nullptr, rlo, rhi, rpre);
         }
@@ -1781,6 +1824,24 @@ static hipError_t launch_conv_halo4_t(const ConvArgs& a, hipStream_t s) {
     // persistent tiles with a STATIC stride measured 6-8 % slower on every layer (r01); HCTR_PERSIST=2 draws tiles
     // from an atomic queue instead (a.tile_counter, zeroed by the engine once per forward)
     static const int persist = [] { const char* e = getenv("HCTR_PERSIST"); return e ? atoi(e) : 0; }();
+    if constexpr (!SPLIT) {
+        // conv2 of an identity block with the residual fetched in the prologue (RESPRE instance): A/B switch HCTR_RESPRE=1,
+        // OFF by default - measured 126.7 vs 125.4 ms per step (three interleaved rounds): the fetch costs the same ~4 us
+        // in the prologue as in the epilogue, and the instance has no room for the next-tap fragment prefetch
+        static const int respre = [] { const char* e = getenv("HCTR_RESPRE"); return e ? atoi(e) : 0; }();
+        if (respre && persist == 0 && a.resid != nullptr && a.se_scale != nullptr) {
+            static bool done_rp[64] = {};
+            hipError_t e0 = raise_lds_limit((const void*)conv3x3_halo4_kernel<GEOM, false, false, false, false, true>,
+                                            kHalo4LdsTotal, done_rp);
+            if (e0 != hipSuccess) return e0;
+            static const int dbg = env_dbg();
+            ConvArgs b = a;
+            b.dbg |= dbg;
+            hipLaunchKernelGGL((conv3x3_halo4_kernel<GEOM, false, false, false, false, true>), dim3(a.mtiles * a.ntiles),
+                               dim3(256), kHalo4LdsTotal, s, b);
+            return hipGetLastError();
+        }
+    }
     if (persist == 0 || (persist == 2 && a.tile_counter == nullptr)) return launch_conv_halo4_tp<GEOM, SPLIT, false>(a, s);
     ConvArgs b = a;
     if (persist != 2) b.tile_counter = nullptr;

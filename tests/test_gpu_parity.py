@@ -572,7 +572,7 @@ def test_full_size_config2_properties(engine, codec, synth):
 @pytest.mark.parametrize("env", [{"HCTR_HALO": "0"}, {"HCTR_HALO": "1"}, {"HCTR_HALO": "0", "HCTR_PIPE": "1"},
                                  {"HCTR_FUSE_SE": "0"}, {"HCTR_HALO": "0", "HCTR_BIG_TILES": "0"},
                                  {"HCTR_PERSIST": "1"}, {"HCTR_PERSIST": "2"}, {"HCTR_FUSE_ARGMAX": "0"}, {"HCTR_FUSE_DS": "0"},
-                                 {"HCTR_FUSE_STEM": "0"}, {"HCTR_WS_ALIAS": "1"}, {"HCTR_HALFHALO": "1"}, {"HCTR_HALFHALO": "0"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+                                 {"HCTR_FUSE_STEM": "0"}, {"HCTR_WS_ALIAS": "1"}, {"HCTR_HALFHALO": "1"}, {"HCTR_RESPRE": "1"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_alternative_kernel_paths(env):
     """The A/B kernels (generic 64x256/128x128/256x256 tiles, 8-wave halo, interleaved pipe, unfused SE,
     persistent tiles) stay correct: same fixture and tolerances as the default path. Kernel selection is
