@@ -1067,6 +1067,9 @@ constexpr int kHalo4Lds = 2 * 16384 + kHaloBytes;          // 78848
 #ifndef BPRE_AT
 #define BPRE_AT 4      // ... behind the MFMAs of this group (4..7)
 #endif
+#ifndef DS_BPRE
+#define DS_BPRE 0      // BPRE in the main loop of the fused-downsample instance too (spills 32 bytes per lane as of this writing)
+#endif
 #ifndef RESPRE_BPRE
 #define RESPRE_BPRE 0  // BPRE in the residual-in-prologue instances too (spills eight halo offsets as of this writing)
 #endif
@@ -1474,7 +1477,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 const int tap1 = more ? (wrap ? 0 : tap + 1) : 0;
                 const int kc1 = more ? (wrap ? kc + 1 : kc) : 0;
                 const char* wsrc = more ? cur.wb : nwb;
-                const bool bpre = LEAN && BPRE && !DSFUSE && !SPLIT && !PERSIST && !(RESPRE && !RESPRE_BPRE);      // (the others would spill)
+                const bool bpre = LEAN && BPRE && !(DSFUSE && !DS_BPRE) && !SPLIT && !PERSIST && !(RESPRE && !RESPRE_BPRE);      // (the others would spill)
                 const char *nbe = nullptr, *nbo = nullptr;
                 if (bpre && tap < 8) b_ptrs(tap + 1, nbe, nbo);
                 mma_step(smem + ((kbase + k) & 1) * 16384, be, bo, [&] {
