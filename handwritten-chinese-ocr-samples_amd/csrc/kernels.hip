@@ -1477,7 +1477,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 const int tap1 = more ? (wrap ? 0 : tap + 1) : 0;
                 const int kc1 = more ? (wrap ? kc + 1 : kc) : 0;
                 const char* wsrc = more ? cur.wb : nwb;
-                const bool bpre = LEAN && BPRE && !(DSFUSE && !DS_BPRE) && !SPLIT && !PERSIST && !(RESPRE && !RESPRE_BPRE);      // (the others would spill)
+                const bool bpre = LEAN && BPRE && !(DSFUSE && !DS_BPRE) && !SPLIT && !PERSIST && !STAMP && !(RESPRE && !RESPRE_BPRE);      // (the others would spill)
                 const char *nbe = nullptr, *nbo = nullptr;
                 if (bpre && tap < 8) b_ptrs(tap + 1, nbe, nbo);
                 mma_step(smem + ((kbase + k) & 1) * 16384, be, bo, [&] {
