@@ -127,6 +127,23 @@ __device__ __forceinline__ void glds16x4_asm_s(const char* s0, const char* s1, c
                  : "memory");
 }
 
+// Four pieces with ONE base, four per-lane offsets and LDS addresses LSTRIDE apart (halo rows): M0 is stepped inside the
+// statement, so it takes two scalar inputs instead of five
+template <int LSTRIDE>
+__device__ __forceinline__ void glds16x4v_asm_s(const char* sbase, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, char* d0) {
+    const uint32_t l0 = (uint32_t)(uintptr_t)((lptr_t)d0);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(l0), "i"(LSTRIDE)
+                 : "memory", "scc");
+}
+
 // -------------------------------------------------------------------------------------------
 // Shared epilogue of the MFMA conv kernels: + folded-BN bias, optional SE partial sums, ReLU,
 // (2,1) max-pool, zeroing of columns >= W, fp16 NHWC store (or fp32 rows in linear mode).
@@ -1067,6 +1084,15 @@ constexpr int kHalo4Lds = 2 * 16384 + kHaloBytes;          // 78848
 #ifndef BPRE_AT
 #define BPRE_AT 4      // ... behind the MFMAs of this group (4..7)
 #endif
+#ifndef EARLY_HALO
+#define EARLY_HALO 1   // (with LEAN, plain f16 instances) next chunk's halo reload issued inside the last tap, see the tap loop
+#endif
+#ifndef EARLY_LGKM
+#define EARLY_LGKM 0
+#endif
+#ifndef EARLY_AT
+#define EARLY_AT 1     // ... behind this MFMA group of tap 8
+#endif
 #ifndef DS_BPRE
 #define DS_BPRE 0      // BPRE in the main loop of the fused-downsample instance too (spills 32 bytes per lane as of this writing)
 #endif
@@ -1104,6 +1130,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     const int cin = a.Cin;
     const int nkc = (a.dbg & 64) ? 0 : cin / kBK;       // dbg 64: timing experiment without the K loop
     const int nk = 9 * nkc;
+    constexpr bool kEarly = LEAN && EARLY_HALO && !DSFUSE && !SPLIT && !PERSIST && !STAMP && !RESPRE;
 
     // ---- tiles of this workgroup. Every XCD owns a contiguous run of the (pixel-tile major, cout-tile
     //      minor) order. Non-persistent: one tile per workgroup. Persistent: the workgroups of an XCD
@@ -1278,7 +1305,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         // prefetch from (nbe, nbo).
         f16x8 bq[2][4];
         auto mma_step = [&](const char* wt, const char* be, const char* bo, auto&& stage_next, auto&& stage_piece,
-                            auto&& after_group, bool have_b0 = false, const char* nbe = nullptr, const char* nbo = nullptr) {
+                            auto&& after_group, bool have_b0 = false, const char* nbe = nullptr, const char* nbo = nullptr,
+                            int bhalf_at = BHALF_AT) {
             f16x8 ar[RING][2];
             auto read_a = [&](int g, f16x8 (&dst)[2]) {
                 const int ks = g >> 2, jp = g & 3;
@@ -1306,7 +1334,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 const int ks = g >> 2, jp = g & 3;
                 if (g + RING - 1 < 8) read_a(g + RING - 1, ar[(g + RING - 1) % RING]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (g == BHALF_AT) { read_b(1, bq[1]); __builtin_amdgcn_sched_barrier(0); }
+                if (g == bhalf_at) { read_b(1, bq[1]); __builtin_amdgcn_sched_barrier(0); }
                 if (!(NOPRIO) && (PRIO_MODE == 0 || PRIO_MODE == 3)) __builtin_amdgcn_s_setprio(1);
                 if (PRIO_MODE == 2) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
@@ -1387,6 +1415,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             if (first) {
                 stage_halo(cur.xb, 0);
                 stage_weights(cur.wb, 0, 0, 0);
+                if (kEarly) {
+                    // EARLY_HALO: the twelve piece offsets are not kept in registers through the K loop; their lane-row part
+                    // (hy * in_sh + hx * cin, the same for the eight lanes of an LDS row) goes into a table in the epilogue's
+                    // scratch (unused until the loop ends), 4 waves x 12 pieces x 8 rows x 4 B = 1.5 KB; the lane's own 16-byte
+                    // chunk term is added back when a piece is issued
+                    uint32_t* htab = (uint32_t*)(smem + kHalo4Lds);
+                    if ((lane & 7) == 0) {
+                        const uint32_t cp0 = (uint32_t)((lane >> 3) & 7) << 4;           // chunk term of lane & 7 == 0
+#pragma unroll
+                        for (int r = 0; r < 12; ++r) htab[(wv * 12 + r) * 8 + (lane >> 3)] = hoff[r] - cp0;
+                    }
+                }
                 first = false;
                 if (STAMP) {
                     stamp(1);
@@ -1480,6 +1520,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 const bool bpre = LEAN && BPRE && !(DSFUSE && !DS_BPRE) && !SPLIT && !PERSIST && !STAMP && !(RESPRE && !RESPRE_BPRE);      // (the others would spill)
                 const char *nbe = nullptr, *nbo = nullptr;
                 if (bpre && tap < 8) b_ptrs(tap + 1, nbe, nbo);
+                const bool early = kEarly;
+                const bool reload = kEarly ? next_chunk : ((next_chunk || has_next) && !(a.dbg & 32));
                 mma_step(smem + ((kbase + k) & 1) * 16384, be, bo, [&] {
                     // the next K step's weights into the other buffer; on a tile's last step that is the
                     // next tile's first step (persistent variant only).
@@ -1499,10 +1541,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 }, [&](int i) {
                     if (more || has_next) stage_weights_piece(wsrc, kc1, tap1, (kbase + k + 1) & 1, i);
                 }, [&](int g) {
-                    if (bpre && tap == 8 && g >= 4) unpack_hoff(3 * (g - 4), (uint32_t)a.in_sh * 2u, (uint32_t)cin * 2u);
-                }, bpre && tap > 0, nbe, nbo);
+                    if (bpre && !early && tap == 8 && g >= 4) unpack_hoff(3 * (g - 4), (uint32_t)a.in_sh * 2u, (uint32_t)cin * 2u);
+                    if (early && tap == 8 && g == EARLY_AT && reload) {
+                        // EARLY_HALO: the last tap reads its second-half pixel fragments at group 0, so after group EARLY_AT
+                        // every fragment of the chunk is in registers: one extra barrier, and the next chunk's halo streams
+                        // in during the remaining MFMA groups instead of after them
+                        // (in-order LDS returns: with EARLY_LGKM = 2 only the two weight-fragment reads issued after the
+                        // pixel fragments may still be in flight)
+                        if (EARLY_LGKM == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        // pieces wv + 4r: r <= 10 exist for every wave (45 pieces), r = 11 for wave 0 only
+                        static_assert(kHaloPieces == 45, "halo piece count");
+                        const char* hsrc = (next_chunk ? cur.xb + (int64_t)(kc + 1) * (kBK * 2) : nxb);
+                        char* d = smem + 32768 + wv * 1024;
+                        int ln = lane;
+                        asm volatile("" : "+v"(ln));                       // (nothing of this is hoisted out of the loop)
+                        const uint32_t* hrow = (const uint32_t*)(smem + kHalo4Lds) + wv * 96 + (ln >> 3);
+                        const uint32_t cpl = (uint32_t)((ln ^ (ln >> 3)) & 7) << 4;
+                        uint32_t ho[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ho[r] = hrow[r * 8] + cpl;
+                        glds16x4v_asm_s<4096>(hsrc, ho[0], ho[1], ho[2], ho[3], d);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ho[r] = hrow[(4 + r) * 8] + cpl;
+                        glds16x4v_asm_s<4096>(hsrc, ho[0], ho[1], ho[2], ho[3], d + 16384);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ho[r] = hrow[(8 + r) * 8] + cpl;
+#pragma unroll
+                        for (int r = 8; r < 11; ++r) glds16_asm_s(hsrc, ho[r - 8], d + r * 4096);
+                        if (wv == 0) glds16_asm_s(hsrc, ho[3], d + 11 * 4096);
+                    }
+                }, bpre && tap > 0, nbe, nbo, (early && tap == 8) ? 0 : BHALF_AT);
             }
-            if ((next_chunk || has_next) && !(a.dbg & 32)) {     // dbg 32: timing experiment without the reload
+            if ((next_chunk || has_next) && !(a.dbg & 32) && !kEarly) {     // dbg 32: timing experiment without the reload
                 // single halo buffer: every wave has consumed its last B fragments of this chunk (they fed
                 // the MFMAs above), so after this barrier the buffer may be overwritten - with the next
                 // chunk, or with the next tile's first chunk (whose latency then hides behind the epilogue).
