@@ -1130,7 +1130,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     const int cin = a.Cin;
     const int nkc = (a.dbg & 64) ? 0 : cin / kBK;       // dbg 64: timing experiment without the K loop
     const int nk = 9 * nkc;
-    constexpr bool kEarly = LEAN && EARLY_HALO && !DSFUSE && !SPLIT && !PERSIST && !STAMP && !RESPRE;
+    // (not with RTOUCH builds: the pre-touch experiment lands its dummy loads in the same LDS scratch as the offset table;
+    //  not in persistent instances: their epilogue overwrites the table after every tile)
+    constexpr bool kEarly = LEAN && EARLY_HALO && !RTOUCH && !DSFUSE && !SPLIT && !PERSIST && !STAMP && !RESPRE;
 
     // ---- tiles of this workgroup. Every XCD owns a contiguous run of the (pixel-tile major, cout-tile
     //      minor) order. Non-persistent: one tile per workgroup. Persistent: the workgroups of an XCD
