@@ -1087,6 +1087,9 @@ constexpr int kHalo4Lds = 2 * 16384 + kHaloBytes;          // 78848
 #ifndef EARLY_HALO
 #define EARLY_HALO 1   // (with LEAN, plain f16 instances) next chunk's halo reload issued inside the last tap, see the tap loop
 #endif
+#ifndef SPLIT_FAST
+#define SPLIT_FAST 1   // fragment prefetch + early halo request in the f16x3 instances too (their K loop is the same code)
+#endif
 #ifndef EARLY_LGKM
 #define EARLY_LGKM 0
 #endif
@@ -1094,7 +1097,7 @@ constexpr int kHalo4Lds = 2 * 16384 + kHaloBytes;          // 78848
 #define EARLY_AT 1     // ... behind this MFMA group of tap 8
 #endif
 #ifndef DS_BPRE
-#define DS_BPRE 0      // BPRE in the main loop of the fused-downsample instance too (spills 32 bytes per lane as of this writing)
+#define DS_BPRE 1      // fragment prefetch + early halo request in the main loop of the fused-downsample instances too
 #endif
 #ifndef RESPRE_BPRE
 #define RESPRE_BPRE 0  // BPRE in the residual-in-prologue instances too (spills eight halo offsets as of this writing)
@@ -1132,7 +1135,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
     const int nk = 9 * nkc;
     // (not with RTOUCH builds: the pre-touch experiment lands its dummy loads in the same LDS scratch as the offset table;
     //  not in persistent instances: their epilogue overwrites the table after every tile)
-    constexpr bool kEarly = LEAN && EARLY_HALO && !RTOUCH && !DSFUSE && !SPLIT && !PERSIST && !STAMP && !RESPRE;
+    constexpr bool kEarly = LEAN && EARLY_HALO && !RTOUCH && !(DSFUSE && !DS_BPRE) && !(SPLIT && !SPLIT_FAST) && !PERSIST && !STAMP && !RESPRE;
 
     // ---- tiles of this workgroup. Every XCD owns a contiguous run of the (pixel-tile major, cout-tile
     //      minor) order. Non-persistent: one tile per workgroup. Persistent: the workgroups of an XCD
@@ -1250,6 +1253,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
         for (int r = r0; r < r0 + 3; ++r) {
             const uint32_t pk = hpk[r >> 1] >> ((r & 1) * 16);
             hoff[r] = ((pk >> 8) & 0xff) * insh2 + (pk & 0xff) * cin2 + hcp16;
+        }
+    };
+    // EARLY_HALO: the twelve piece offsets are not kept in registers through the K loop; their lane-row part
+    // (hy * in_sh + hx * cin, the same for the eight lanes of an LDS row) goes into a table in the epilogue's scratch
+    // (unused until the loop ends), 4 waves x 12 pieces x 8 rows x 4 B = 1.5 KB; the lane's own 16-byte chunk term is added
+    // back when a piece is issued. Called right after the lane_offsets() of the tensor the K loop reads.
+    auto write_halo_table = [&]() {
+        uint32_t* htab = (uint32_t*)(smem + kHalo4Lds);
+        if ((lane & 7) == 0) {
+            const uint32_t cp0 = (uint32_t)((lane >> 3) & 7) << 4;           // chunk term of lane & 7 == 0
+#pragma unroll
+            for (int r = 0; r < 12; ++r) htab[(wv * 12 + r) * 8 + (lane >> 3)] = hoff[r] - cp0;
         }
     };
     const int hbuf = 32768 + wrow * (S * 128);
@@ -1394,6 +1409,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 } else {
                     lane_offsets(cin, a.in_sh, woff, true);   // from here on the halo holds conv2's input t
                     stage_halo(cur.xb, 0);
+                    if (kEarly) write_halo_table();
                 }
             }
             kbase = nds;
@@ -1417,18 +1433,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
             if (first) {
                 stage_halo(cur.xb, 0);
                 stage_weights(cur.wb, 0, 0, 0);
-                if (kEarly) {
-                    // EARLY_HALO: the twelve piece offsets are not kept in registers through the K loop; their lane-row part
-                    // (hy * in_sh + hx * cin, the same for the eight lanes of an LDS row) goes into a table in the epilogue's
-                    // scratch (unused until the loop ends), 4 waves x 12 pieces x 8 rows x 4 B = 1.5 KB; the lane's own 16-byte
-                    // chunk term is added back when a piece is issued
-                    uint32_t* htab = (uint32_t*)(smem + kHalo4Lds);
-                    if ((lane & 7) == 0) {
-                        const uint32_t cp0 = (uint32_t)((lane >> 3) & 7) << 4;           // chunk term of lane & 7 == 0
-#pragma unroll
-                        for (int r = 0; r < 12; ++r) htab[(wv * 12 + r) * 8 + (lane >> 3)] = hoff[r] - cp0;
-                    }
-                }
+                if (kEarly) write_halo_table();
                 first = false;
                 if (STAMP) {
                     stamp(1);
@@ -1519,7 +1524,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(const ConvArgs a)
                 const int tap1 = more ? (wrap ? 0 : tap + 1) : 0;
                 const int kc1 = more ? (wrap ? kc + 1 : kc) : 0;
                 const char* wsrc = more ? cur.wb : nwb;
-                const bool bpre = LEAN && BPRE && !(DSFUSE && !DS_BPRE) && !SPLIT && !PERSIST && !STAMP && !(RESPRE && !RESPRE_BPRE);      // (the others would spill)
+                const bool bpre = LEAN && BPRE && !(DSFUSE && !DS_BPRE) && !(SPLIT && !SPLIT_FAST) && !PERSIST && !STAMP && !(RESPRE && !RESPRE_BPRE);      // (the others would spill)
                 const char *nbe = nullptr, *nbo = nullptr;
                 if (bpre && tap < 8) b_ptrs(tap + 1, nbe, nbo);
                 const bool early = kEarly;
